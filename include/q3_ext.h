@@ -1,0 +1,156 @@
+/*
+ * q3_ext.h -- entry points of libq3hip.so beyond the reference's own symbols.
+ *
+ * The reference has no loader-independent way to build a Model, no synthetic
+ * checkpoints, no timers and no multi-GPU knob; everything a harness needs
+ * around forward() lives here, behind plain C types.
+ *
+ * Host-side pieces (plain C, no GPU needed):
+ *   q3_model_open/close   own reader of the reference's `.bin` layout
+ *                         (reference src/model.c:451-500, format Appendix A of SURVEY.md)
+ *   q3_synth_write        deterministic random-init checkpoint writer
+ *                         (the exporter qwen3/weights.py:249-381 defines the format)
+ *   q3_argmax             greedy pick over host logits
+ *
+ * Device-side pieces (need an MI355X; fail loudly otherwise):
+ *   q3_device_*           explicit attach/detach of the per-Model device state
+ *                         that forward() otherwise creates lazily
+ *   q3_op_*               single kernels on host arrays, for op-level parity tests
+ *   q3_tap_*              per-layer residual read-back for layer-level parity
+ *   q3_prof_*             HIP-event timing of the GEMV kernels on the launch stream
+ *   q3_generate_greedy    on-device greedy loop (no host round trip per token)
+ *   q3_pipeline_*         layer pipeline over several GPUs, one process per GPU
+ */
+#ifndef Q3_EXT_H
+#define Q3_EXT_H
+
+#include "q3_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- host --- */
+
+/* flags for q3_model_open */
+#define Q3_OPEN_DEFAULT 0
+#define Q3_OPEN_HOST_STATE 1  /* also allocate the reference's host scratch, host KV
+                                 cache and fp32 embedding table (model.c:199-206,
+                                 321-406) so that CPU code written against the
+                                 reference structs (the oracle) can run on it */
+
+/* Map `path`, check the header, carve the weight views.  seq_len is lowered
+ * to override_seq_len when 0 < override <= header value (model.c:74-76).
+ * state.logits is always allocated (page-aligned).  NULL on failure. */
+Model* q3_model_open(const char* path, int override_seq_len, int flags);
+void q3_model_close(Model* m);
+
+typedef struct Q3SynthSpec {
+    int dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size, seq_len, head_dim;
+    int shared_classifier;
+    uint64_t seed;
+    float sigma;          /* target std of dequantised weights, 0 -> 0.02 */
+} Q3SynthSpec;
+
+/* Fill a spec from a name: "tiny", "small", "0.6B", "1.7B", "4B", "8B".
+ * Returns 0, or -1 for an unknown name. */
+int q3_synth_preset(const char* name, Q3SynthSpec* spec);
+/* Write a random-init checkpoint in the reference's .bin layout.
+ * Same spec + seed => same bytes on every machine.  Returns 0 on success. */
+int q3_synth_write(const char* path, const Q3SynthSpec* spec);
+/* Bytes q3_synth_write will produce for `spec`. */
+int64_t q3_synth_bytes(const Q3SynthSpec* spec);
+/* 64-bit FNV-1a of a file, for fixture checksums. */
+uint64_t q3_file_checksum(const char* path);
+
+int q3_argmax(const float* logits, int n);
+
+/* Algorithmic HBM bytes of one decode step with T cached positions before
+ * it; and of one GEMV launch of shape d x n. */
+double q3_bytes_per_token(const ModelParams* p, int T);
+double q3_gemv_bytes(int d, int n);
+
+/* -------------------------------------------------------------- device --- */
+
+/* Number of visible HIP devices (0 when there is no GPU / no driver). */
+int q3_device_count(void);
+
+/* Create (or return) the device state of `m`: weights uploaded, KV cache,
+ * RoPE table, launch graph.  forward() calls this lazily.  Environment:
+ *   Q3_DEVICE=<n>      HIP device ordinal (default: LOCAL_RANK or 0)
+ *   Q3_GRAPH=0|1       replay the step through a hipGraph (default 1)
+ * Returns 0 on success; on failure prints the reason and returns -1. */
+int q3_device_attach(Model* m);
+void q3_device_detach(Model* m);
+void q3_device_sync(Model* m);
+
+/* One decode step without the logits copy: logits stay on the device.
+ * Pair with q3_logits_fetch() or q3_device_argmax(). */
+void q3_forward_device(Model* m, int token, int pos);
+void q3_logits_fetch(Model* m);           /* D2H into m->state.logits, synchronous */
+int q3_device_argmax(Model* m);           /* argmax of the device logits */
+
+/* Greedy decode on the device: feeds `token` at `pos`, then its own argmax,
+ * for n steps; out_tokens[i] is the token chosen after step i.  Logits are
+ * copied to the host only after the last step. */
+int q3_generate_greedy(Model* m, int token, int pos, int n, int* out_tokens);
+
+/* Fill positions [0, T) of every layer's device KV cache with finite
+ * pseudo-random values (timing of long contexts without T real steps). */
+void q3_kv_fill_random(Model* m, int T, uint64_t seed);
+
+/* Per-layer tap: after q3_tap_enable(m, 1) every forward() also copies the
+ * residual after each layer into a host buffer of n_layers*dim floats. */
+void q3_tap_enable(Model* m, int on);
+const float* q3_tap_data(Model* m);
+
+/* Layer-level teacher forcing: run only layer `layer` at `pos` on the device,
+ * starting from the host residual x_in[dim], and return the residual after
+ * the layer in x_out[dim].  Uses and updates the device KV cache at `pos`. */
+void q3_layer_step(Model* m, int layer, int pos, const float* x_in, float* x_out);
+
+/* ---- single kernels on host arrays (op-level parity; each call uploads,
+ *      launches on the library stream and downloads) ------------------- */
+void q3_op_quantize(const float* x, int n, int8_t* q, float* s);
+void q3_op_rmsnorm_quantize(const float* x, const float* w, int n, float* normed,
+                            int8_t* q, float* s);
+void q3_op_gemv(const int8_t* wq, const float* ws, const int8_t* xq, const float* xs,
+                int n, int d, float* out);
+void q3_op_headnorm_rope(float* heads, int n_heads, int head_dim, const float* w, int pos);
+/* q[n_heads][hd]; kcache/vcache [T][n_kv][hd] (reference cache layout of one
+ * layer, model.c:360-361 / forward.c:148); out[n_heads][hd]. */
+void q3_op_attention(const float* q, const float* kcache, const float* vcache, int T,
+                     int n_heads, int n_kv_heads, int head_dim, float* out);
+void q3_op_swiglu(const float* gate, const float* up, int n, float* out);
+void q3_op_expf(const float* x, int n, float* out);
+
+/* ---- timing ----------------------------------------------------------- */
+typedef struct Q3ProfEntry {
+    const char* name;     /* kernel class: "qkv", "attn", "wo", "gateup", "down", "cls", ... */
+    int64_t launches;
+    double ms_total;      /* sum of HIP-event elapsed times on the launch stream */
+    double bytes_per_launch; /* algorithmic bytes of one launch */
+} Q3ProfEntry;
+/* Event-bracket every kernel launch of subsequent forward() calls (forces the
+ * non-graph path while on). */
+void q3_prof_enable(Model* m, int on);
+void q3_prof_reset(Model* m);
+int q3_prof_get(Model* m, Q3ProfEntry* out, int max_entries);
+
+/* ---- multi-GPU layer pipeline (one process per GPU) -------------------- */
+#define Q3_PIPE_ID_BYTES 128
+/* Rank 0 creates the RCCL unique id; the harness broadcasts the bytes. */
+int q3_pipeline_unique_id(void* id_bytes);
+/* Join the communicator; must be called before q3_device_attach().  Stage
+ * `rank` owns a contiguous block of layers (rank 0 also the embedding, the
+ * last rank the final norm + classifier). */
+int q3_pipeline_init(int rank, int world, const void* id_bytes);
+void q3_pipeline_layers(const ModelParams* p, int rank, int world, int* first, int* count);
+void q3_pipeline_shutdown(void);
+
+const char* q3_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Q3_EXT_H */

@@ -1,0 +1,441 @@
+/*
+ * q3_oracle.c -- CPU restatement of the reference's forward pass.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under qwen3.c_amd/ links, loads or calls
+ * this file; it is used by tests/, by __graft_entry__.smoke() and by the
+ * cpu_baseline leg of bench.py, always as the checker / the CPU number, never
+ * as the product path.
+ *
+ * Two modes, selected with orc_set_mode():
+ *
+ *   ORC_REF  (0)  the reference's arithmetic in the reference's order, one
+ *                 thread: every loop below cites the reference lines it
+ *                 restates.  PINNED: tests/test_oracle_vs_reference.py checks
+ *                 it bit-for-bit against the reference itself compiled from
+ *                 /root/reference (oracle/_ref/libqwen3_ref.so, -O2 -DNDEBUG,
+ *                 OMP_NUM_THREADS=1) and tests/golden/ holds logits captured
+ *                 from that build (tests/golden/make_golden.py).
+ *
+ *   ORC_TREE (1)  identical per-operation arithmetic, but every fp32 sum uses
+ *                 the fixed reduction trees of qwen3.c_amd/csrc/q3_numerics.h
+ *                 and expf is q3_expf.  This is what the HIP kernels compute,
+ *                 so GPU == ORC_TREE bit-for-bit, and ORC_TREE is tied to
+ *                 ORC_REF by tolerance tests (1e-6 per op, 1e-5 end-to-end on
+ *                 fixtures where no int8 code flips; SURVEY.md 8(c')).
+ *
+ * Built with -O2 -ffp-contract=off -fno-fast-math so that no multiply-add is
+ * fused and no sum is re-associated.  OpenMP is used only across matmul rows
+ * and attention heads (independent outputs => still deterministic).
+ */
+#include "q3_abi.h"
+#include "q3_numerics.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+enum { ORC_REF = 0, ORC_TREE = 1 };
+
+static int g_mode = ORC_REF;
+static int g_threads = 1;
+static float* g_tap = NULL;
+
+void orc_set_mode(int mode) { g_mode = mode ? ORC_TREE : ORC_REF; }
+int orc_get_mode(void) { return g_mode; }
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int orc_get_threads(void) { return g_threads; }
+/* residual after every layer is copied to tap[l*dim ..] when non-NULL */
+void orc_set_tap(float* tap) { g_tap = tap; }
+
+float orc_expf(float x) { return g_mode == ORC_TREE ? q3_expf(x) : expf(x); }
+
+/* ------------------------------------------------------------ trees ---- */
+
+/* butterfly over n (power of two) partials: t[i] += t[i^m], m = n/2 .. 1 */
+static float butterfly(float* t, int n) {
+    float tmp[64];
+    for (int m = n >> 1; m >= 1; m >>= 1) {
+        for (int i = 0; i < n; i++) tmp[i] = t[i] + t[i ^ m];
+        memcpy(t, tmp, (size_t)n * sizeof(float));
+    }
+    return t[0];
+}
+
+/* SUM256 of f(i), i < n: see q3_numerics.h */
+static float sum256_sq(const float* x, int n) {
+    float P[256];
+    for (int j = 0; j < 256; j++) P[j] = 0.0f;
+    for (int i = 0; i < n; i++) {
+        const float prod = x[i] * x[i];
+        P[i & 255] = P[i & 255] + prod;
+    }
+    float lane[64];
+    for (int l = 0; l < 64; l++) {
+        lane[l] = (P[4 * l] + P[4 * l + 1]) + (P[4 * l + 2] + P[4 * l + 3]);
+    }
+    return butterfly(lane, 64);
+}
+
+static float sum256(const float* x, int n) {
+    float P[256];
+    for (int j = 0; j < 256; j++) P[j] = 0.0f;
+    for (int i = 0; i < n; i++) P[i & 255] = P[i & 255] + x[i];
+    float lane[64];
+    for (int l = 0; l < 64; l++) {
+        lane[l] = (P[4 * l] + P[4 * l + 1]) + (P[4 * l + 2] + P[4 * l + 3]);
+    }
+    return butterfly(lane, 64);
+}
+
+/* ------------------------------------------------------------- q8 ------ */
+
+/* reference src/q8.c:5-30 -- no sum inside, so one implementation serves both modes */
+void orc_q8_quantize(Q8Tensor* qt, const float* x, int n, int block_size) {
+    const int groups = n / block_size;
+    for (int g = 0; g < groups; g++) {
+        const float* xg = x + (size_t)g * block_size;
+        int8_t* qg = qt->q + (size_t)g * block_size;
+        float wmax = fabsf(xg[0]);
+        for (int i = 1; i < block_size; i++) wmax = fmaxf(wmax, fabsf(xg[i]));
+        const float scale = (wmax == 0.0f) ? 1e-6f : (wmax / Q8_MAX);
+        qt->s[g] = scale;
+        for (int i = 0; i < block_size; i++) {
+            const float q = xg[i] / scale;
+            qg[i] = (int8_t)fminf(fmaxf(roundf(q), -Q8_MAX), Q8_MAX);
+        }
+    }
+}
+
+/* reference src/q8.c:32-36 */
+void orc_q8_dequantize(const Q8Tensor* qt, float* x, int n, int block_size) {
+    for (int i = 0; i < n; i++) x[i] = qt->q[i] * qt->s[i / block_size];
+}
+
+/* ---------------------------------------------------------- rmsnorm ---- */
+
+/* reference src/forward.c:12-28 */
+void orc_rmsnorm(float* out, const float* x, const float* w, int size) {
+    float sos;
+    if (g_mode == ORC_TREE) {
+        sos = sum256_sq(x, size);
+    } else {
+        sos = 0.0f;
+        for (int i = 0; i < size; i++) sos += x[i] * x[i];
+    }
+    sos = 1.0f / sqrtf((sos / size) + 1e-6f);
+    for (int i = 0; i < size; i++) out[i] = w[i] * (sos * x[i]);
+}
+
+/* ---------------------------------------------------------- softmax ---- */
+
+/* reference src/forward.c:34-77 (the NaN/Inf diagnostics are not arithmetic) */
+void orc_softmax(float* x, int size) {
+    float max_val = x[0];
+    for (int i = 1; i < size; i++) {
+        if (x[i] > max_val) max_val = x[i];
+    }
+    if (g_mode == ORC_TREE) {
+        for (int i = 0; i < size; i++) x[i] = q3_expf(x[i] - max_val);
+        const float sum = sum256(x, size);
+        for (int i = 0; i < size; i++) x[i] /= sum;
+        return;
+    }
+    float sum = 0.0f;
+    for (int i = 0; i < size; i++) {
+        x[i] = expf(x[i] - max_val);
+        sum += x[i];
+    }
+    for (int i = 0; i < size; i++) x[i] /= sum;
+}
+
+/* ----------------------------------------------------------- matmul ---- */
+
+/* reference src/forward.c:79-101 */
+void orc_matmul(float* out, const Q8Tensor* x, const Q8Tensor* w, int n, int d, int block_size) {
+    const int groups = n / block_size;
+    const int mode = g_mode;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int i = 0; i < d; i++) {
+        const int8_t* wr = w->q + (size_t)i * n;
+        const float* ws = w->s + (size_t)i * groups;
+        float col[Q3_MM_COLS];
+        for (int c = 0; c < Q3_MM_COLS; c++) col[c] = 0.0f;
+        float val = 0.0f;
+        for (int g = 0; g < groups; g++) {
+            int32_t dot = 0;
+            const int8_t* xq = x->q + (size_t)g * block_size;
+            const int8_t* wq = wr + (size_t)g * block_size;
+            for (int k = 0; k < block_size; k++) dot += xq[k] * wq[k];
+            const float p = ((float)dot) * ws[g] * x->s[g];
+            if (mode == ORC_TREE) {
+                col[g % Q3_MM_COLS] = col[g % Q3_MM_COLS] + p;
+            } else {
+                val += p;
+            }
+        }
+        out[i] = (mode == ORC_TREE) ? butterfly(col, Q3_MM_COLS) : val;
+    }
+}
+
+/* ------------------------------------------------------------- rope ---- */
+
+/* reference src/forward.c:104-118; libm on the host in both modes (the device
+ * reads a table built with these very calls) */
+void orc_rope_table(int head_dim, int pos, float* cos_out, float* sin_out) {
+    const int half_dim = head_dim / 2;
+    for (int i = 0; i < half_dim; i++) {
+        const float angle = pos * powf(1e6f, -(float)i / half_dim);
+        cos_out[i] = cosf(angle);
+        sin_out[i] = sinf(angle);
+    }
+}
+
+void orc_rotary(float* x, int head_dim, int pos) {
+    const int half_dim = head_dim / 2;
+    for (int i = 0; i < half_dim; i++) {
+        const float angle = pos * powf(1e6f, -(float)i / half_dim);
+        const float cos_a = cosf(angle), sin_a = sinf(angle);
+        const float real = x[i];
+        const float imag = x[i + half_dim];
+        x[i] = real * cos_a - imag * sin_a;
+        x[i + half_dim] = real * sin_a + imag * cos_a;
+    }
+}
+
+/* ----------------------------------------------------------- swiglu ---- */
+
+/* reference src/forward.c:122-139 */
+float orc_sigmoid(float x) { return 1.0f / (1.0f + orc_expf(-x)); }
+float orc_silu(float x) { return x * orc_sigmoid(x); }
+void orc_swiglu(float* x1, const float* x3, int size) {
+    for (int i = 0; i < size; i++) x1[i] = orc_silu(x1[i]) * x3[i];
+}
+
+/* -------------------------------------------------------- attention ---- */
+
+/* One query head against T cached positions.  k, v point at this head's slice
+ * of position 0; consecutive positions are `stride` floats apart.
+ * ORC_REF restates reference src/forward.c:155-192 with one thread. */
+static void attend_ref(const float* q, const float* k, const float* v, size_t stride, int T,
+                       int hd, float* scores, float* out) {
+    for (int t = 0; t < T; t++) {
+        const float* kt = k + (size_t)t * stride;
+        float score = 0.0f;
+        for (int j = 0; j < hd; j++) score += q[j] * kt[j];
+        scores[t] = score / sqrtf((float)hd);
+    }
+    orc_softmax(scores, T);
+    float tmp[128];
+    for (int j = 0; j < hd; j++) tmp[j] = 0.0f;
+    for (int t = 0; t < T; t++) {
+        const float* vt = v + (size_t)t * stride;
+        for (int j = 0; j < hd; j++) tmp[j] += scores[t] * vt[j];
+    }
+    for (int j = 0; j < hd; j++) out[j] = 0.0f + tmp[j];
+}
+
+static float dot_tree(const float* q, const float* k, int hd) {
+    float lane[32];
+    for (int l = 0; l < 32; l++) {
+        if (4 * l < hd) {
+            float c = q[4 * l] * k[4 * l];
+            c = c + q[4 * l + 1] * k[4 * l + 1];
+            c = c + q[4 * l + 2] * k[4 * l + 2];
+            c = c + q[4 * l + 3] * k[4 * l + 3];
+            lane[l] = c;
+        } else {
+            lane[l] = 0.0f;
+        }
+    }
+    return butterfly(lane, 32);
+}
+
+/* the chunked tree of q3_numerics.h */
+static void attend_tree(const float* q, const float* k, const float* v, size_t stride, int T,
+                        int hd, float* out) {
+    const int nchunks = (T + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
+    float* m = (float*)malloc((size_t)nchunks * sizeof(float));
+    float* l = (float*)malloc((size_t)nchunks * sizeof(float));
+    float* O = (float*)malloc((size_t)nchunks * 128 * sizeof(float));
+    const float inv = sqrtf((float)hd);
+    for (int c = 0; c < nchunks; c++) {
+        const int t0 = c * Q3_ATT_CHUNK;
+        const int t1 = (t0 + Q3_ATT_CHUNK < T) ? t0 + Q3_ATT_CHUNK : T;
+        float s[Q3_ATT_CHUNK], e[Q3_ATT_CHUNK];
+        float mc = 0.0f;
+        for (int t = t0; t < t1; t++) {
+            s[t - t0] = dot_tree(q, k + (size_t)t * stride, hd) / inv;
+            if (t == t0 || s[t - t0] > mc) mc = s[t - t0];
+        }
+        for (int i = 0; i < Q3_ATT_CHUNK; i++) e[i] = 0.0f;
+        for (int t = t0; t < t1; t++) e[t - t0] = q3_expf(s[t - t0] - mc);
+        float a[Q3_ATT_STREAMS][128];
+        memset(a, 0, sizeof(a));
+        for (int t = t0; t < t1; t++) {
+            const float* vt = v + (size_t)t * stride;
+            float* as = a[t % Q3_ATT_STREAMS];
+            const float et = e[t - t0];
+            for (int j = 0; j < hd; j++) as[j] = as[j] + et * vt[j];
+        }
+        for (int j = 0; j < hd; j++) {
+            O[(size_t)c * 128 + j] = ((a[0][j] + a[1][j]) + (a[2][j] + a[3][j]))
+                                     + ((a[4][j] + a[5][j]) + (a[6][j] + a[7][j]));
+        }
+        m[c] = mc;
+        l[c] = butterfly(e, Q3_ATT_CHUNK);
+    }
+    float M = m[0];
+    for (int c = 1; c < nchunks; c++) {
+        if (m[c] > M) M = m[c];
+    }
+    float Lsum = 0.0f;
+    float A[128];
+    for (int j = 0; j < hd; j++) A[j] = 0.0f;
+    for (int c = 0; c < nchunks; c++) {
+        const float w = q3_expf(m[c] - M);
+        Lsum = Lsum + w * l[c];
+        for (int j = 0; j < hd; j++) A[j] = A[j] + w * O[(size_t)c * 128 + j];
+    }
+    for (int j = 0; j < hd; j++) out[j] = A[j] / Lsum;
+    free(m);
+    free(l);
+    free(O);
+}
+
+/* q[n_heads][hd]; kcache/vcache laid out [T][n_kv][hd] (one layer of the
+ * reference cache, src/forward.c:148,157); out[n_heads][hd] */
+void orc_attention_raw(const float* q, const float* kcache, const float* vcache, int T,
+                       int n_heads, int n_kv_heads, int head_dim, float* out) {
+    const int kv_mul = n_heads / n_kv_heads;
+    const size_t stride = (size_t)n_kv_heads * head_dim;
+    const int mode = g_mode;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int h = 0; h < n_heads; h++) {
+        const float* qh = q + (size_t)h * head_dim;
+        const float* kh = kcache + (size_t)(h / kv_mul) * head_dim;
+        const float* vh = vcache + (size_t)(h / kv_mul) * head_dim;
+        float* oh = out + (size_t)h * head_dim;
+        if (mode == ORC_TREE) {
+            attend_tree(qh, kh, vh, stride, T, head_dim, oh);
+        } else {
+            float* scores = (float*)malloc((size_t)T * sizeof(float));
+            attend_ref(qh, kh, vh, stride, T, head_dim, scores, oh);
+            free(scores);
+        }
+    }
+}
+
+/* reference src/forward.c:141-195: reads state.q and the caches, writes state.x_rms_norm */
+void orc_attention(Model* m, int layer, int pos) {
+    const ModelParams* p = &m->params;
+    ForwardState* s = &m->state;
+    const size_t kvd = (size_t)p->n_kv_heads * p->head_dim;
+    const size_t loff = (size_t)layer * p->seq_len * kvd;
+    orc_attention_raw(s->q, s->k_cache + loff, s->v_cache + loff, pos + 1, p->n_heads,
+                      p->n_kv_heads, p->head_dim, s->x_rms_norm);
+}
+
+/* ---------------------------------------------------------- forward ---- */
+
+/* reference src/forward.c:225-350.  Needs a Model with host state
+ * (q3_model_open(..., Q3_OPEN_HOST_STATE) or the reference's model_create). */
+float* orc_forward(Model* m, int token, int pos) {
+    const ModelParams* p = &m->params;
+    const ModelWeights* w = &m->weights;
+    ForwardState* s = &m->state;
+    const int dim = p->dim, hd = p->head_dim, bs = p->block_size;
+    const int kv_dim = p->n_kv_heads * hd;
+    const int proj_dim = p->n_heads * hd;
+
+    memcpy(s->x, w->fe + (size_t)token * dim, (size_t)dim * sizeof(float));   /* :237 */
+
+    for (int l = 0; l < p->n_layers; l++) {
+        const size_t loff = (size_t)l * p->seq_len * kv_dim;                    /* :244 */
+        s->k = s->k_cache + loff + (size_t)pos * kv_dim;
+        s->v = s->v_cache + loff + (size_t)pos * kv_dim;
+
+        orc_rmsnorm(s->x_rms_norm, s->x, w->att_rms_norm + (size_t)l * dim, dim); /* :254 */
+        orc_q8_quantize(&s->qx, s->x_rms_norm, dim, bs);                         /* :259 */
+        orc_matmul(s->q, &s->qx, w->wq + l, dim, proj_dim, bs);
+        orc_matmul(s->k, &s->qx, w->wk + l, dim, kv_dim, bs);
+        orc_matmul(s->v, &s->qx, w->wv + l, dim, kv_dim, bs);
+
+        const float* gq = w->q_rms_norm + (size_t)l * hd;                        /* :267-280 */
+        const float* gk = w->k_rms_norm + (size_t)l * hd;
+        for (int h = 0; h < p->n_heads; h++) {
+            float* q = s->q + (size_t)h * hd;
+            orc_rmsnorm(q, q, gq, hd);
+            orc_rotary(q, hd, pos);
+        }
+        for (int h = 0; h < p->n_kv_heads; h++) {
+            float* k = s->k + (size_t)h * hd;
+            orc_rmsnorm(k, k, gk, hd);
+            orc_rotary(k, hd, pos);
+        }
+
+        orc_attention(m, l, pos);                                                /* :286 */
+
+        orc_q8_quantize(&s->qx, s->x_rms_norm, proj_dim, bs);                    /* :291-298 */
+        orc_matmul(s->x_rms_norm, &s->qx, w->wo + l, proj_dim, dim, bs);
+        for (int i = 0; i < dim; i++) s->x[i] += s->x_rms_norm[i];
+
+        orc_rmsnorm(s->x_rms_norm, s->x, w->ffn_rms_norm + (size_t)l * dim, dim); /* :303 */
+        orc_q8_quantize(&s->qx, s->x_rms_norm, dim, bs);
+        orc_matmul(s->mlp_in, &s->qx, w->w1 + l, dim, p->hidden_dim, bs);
+        orc_matmul(s->mlp_gate, &s->qx, w->w3 + l, dim, p->hidden_dim, bs);
+        orc_swiglu(s->mlp_in, s->mlp_gate, p->hidden_dim);                       /* :319 */
+
+        orc_q8_quantize(&s->qh, s->mlp_in, p->hidden_dim, bs);                   /* :326-338 */
+        orc_matmul(s->x_rms_norm, &s->qh, w->w2 + l, p->hidden_dim, dim, bs);
+        for (int i = 0; i < dim; i++) s->x[i] += s->x_rms_norm[i];
+
+        if (g_tap) memcpy(g_tap + (size_t)l * dim, s->x, (size_t)dim * sizeof(float));
+    }
+
+    orc_rmsnorm(s->x, s->x, w->out_rms_norm, dim);                               /* :344 */
+    orc_q8_quantize(&s->qx, s->x, dim, bs);
+    orc_matmul(s->logits, &s->qx, w->cls, dim, p->vocab_size, bs);
+    return s->logits;
+}
+
+/* One layer from a given residual, for layer-level teacher forcing. */
+void orc_layer_step(Model* m, int layer, int pos, const float* x_in, float* x_out) {
+    const ModelParams* p = &m->params;
+    const ModelWeights* w = &m->weights;
+    ForwardState* s = &m->state;
+    const int dim = p->dim, hd = p->head_dim, bs = p->block_size, l = layer;
+    const int kv_dim = p->n_kv_heads * hd, proj_dim = p->n_heads * hd;
+    memcpy(s->x, x_in, (size_t)dim * sizeof(float));
+    const size_t loff = (size_t)l * p->seq_len * kv_dim;
+    s->k = s->k_cache + loff + (size_t)pos * kv_dim;
+    s->v = s->v_cache + loff + (size_t)pos * kv_dim;
+    orc_rmsnorm(s->x_rms_norm, s->x, w->att_rms_norm + (size_t)l * dim, dim);
+    orc_q8_quantize(&s->qx, s->x_rms_norm, dim, bs);
+    orc_matmul(s->q, &s->qx, w->wq + l, dim, proj_dim, bs);
+    orc_matmul(s->k, &s->qx, w->wk + l, dim, kv_dim, bs);
+    orc_matmul(s->v, &s->qx, w->wv + l, dim, kv_dim, bs);
+    for (int h = 0; h < p->n_heads; h++) {
+        orc_rmsnorm(s->q + (size_t)h * hd, s->q + (size_t)h * hd, w->q_rms_norm + (size_t)l * hd, hd);
+        orc_rotary(s->q + (size_t)h * hd, hd, pos);
+    }
+    for (int h = 0; h < p->n_kv_heads; h++) {
+        orc_rmsnorm(s->k + (size_t)h * hd, s->k + (size_t)h * hd, w->k_rms_norm + (size_t)l * hd, hd);
+        orc_rotary(s->k + (size_t)h * hd, hd, pos);
+    }
+    orc_attention(m, l, pos);
+    orc_q8_quantize(&s->qx, s->x_rms_norm, proj_dim, bs);
+    orc_matmul(s->x_rms_norm, &s->qx, w->wo + l, proj_dim, dim, bs);
+    for (int i = 0; i < dim; i++) s->x[i] += s->x_rms_norm[i];
+    orc_rmsnorm(s->x_rms_norm, s->x, w->ffn_rms_norm + (size_t)l * dim, dim);
+    orc_q8_quantize(&s->qx, s->x_rms_norm, dim, bs);
+    orc_matmul(s->mlp_in, &s->qx, w->w1 + l, dim, p->hidden_dim, bs);
+    orc_matmul(s->mlp_gate, &s->qx, w->w3 + l, dim, p->hidden_dim, bs);
+    orc_swiglu(s->mlp_in, s->mlp_gate, p->hidden_dim);
+    orc_q8_quantize(&s->qh, s->mlp_in, p->hidden_dim, bs);
+    orc_matmul(s->x_rms_norm, &s->qh, w->w2 + l, p->hidden_dim, dim, bs);
+    for (int i = 0; i < dim; i++) s->x[i] += s->x_rms_norm[i];
+    memcpy(x_out, s->x, (size_t)dim * sizeof(float));
+}
