@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Decode-throughput bench of the MI355X forward() path.
+
+    python bench.py --gpus N --steps K --warmup W [--model 4B] [--context T]
+
+A "step" is one forward(model, token, pos) through the C-ABI (libq3hip.so): the whole
+decode step of the Qwen3 Q8_0 model plus the copy of the logits to the host, with the
+weights and the KV cache already resident in HBM.  Workload: BASELINE.json's headline
+configuration, Qwen3-4B-shaped random-init Q8_0 weights (SURVEY.md 8(d) recipe), greedy
+feedback from token 9707.
+
+N > 1 (launched by torch.distributed.run, one process per GPU): the layers are split
+into N contiguous stages; the residual travels stage to stage by RCCL send/recv over
+xGMI (q3_pipeline_*), and N independent token streams keep every stage busy, so
+`value` = tokens/s summed over the N streams ("weak" scaling: one stream per GPU).
+
+The JSON line also carries
+  roofline      HBM roofline of the dominant kernel (the gate/up GEMV): algorithmic bytes
+                per launch / mean launch duration from HIP events on the launch stream
+  cpu_baseline  the reference's own CPU path (oracle/_ref, upstream -Ofast flags, all
+                host cores) or, when that build is absent, the oracle's port, on a
+                bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+START_TOKEN = 9707
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may use: the affinity mask, capped at the GPU box's per-GPU CPU
+    share (16) -- os.cpu_count() reports the whole host and oversubscribes OpenMP."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("Q3_MAX_CORES", "16"))))
+
+
+def cpu_baseline(path, vocab, budget_s=20.0):
+    """Tokens/s of the CPU path on the host cores of this box (rank 0, N=1 only)."""
+    import numpy as np
+    import q3lib as Q
+    cores = int(os.environ["OMP_NUM_THREADS"])
+    ref = Q.reference_lib(fast=True)
+    first = START_TOKEN % vocab
+    if ref is not None:
+        m = ref.model_create(path.encode(), 256)
+        step = lambda t, p: ref.forward(m, t, p)   # noqa: E731
+        kind = "reference"
+    else:
+        orc, host = Q.oracle_lib(), Q.host_lib()
+        orc.orc_set_mode(Q.ORC_TREE)
+        orc.orc_set_threads(cores)
+        m = host.q3_model_open(path.encode(), 256, 1)
+        step = lambda t, p: orc.orc_forward(m, t, p)   # noqa: E731
+        kind = "port"
+    tok, pos = first, 0
+    t0 = time.perf_counter()
+    lg = step(tok, pos)           # one untimed step (page-in)
+    log(f"[bench] cpu baseline ({kind}, {cores} threads): first step {time.perf_counter() - t0:.2f}s")
+    tok = int(np.ctypeslib.as_array(lg, shape=(vocab,)).argmax()); pos = 1
+    t0 = time.perf_counter()
+    n = 0
+    while n < 1 or (time.perf_counter() - t0 < budget_s and n < 64 and pos < 250):
+        lg = step(tok, pos)
+        tok = int(np.ctypeslib.as_array(lg, shape=(vocab,)).argmax())
+        pos += 1
+        n += 1
+        if n % 4 == 0:
+            log(f"[bench] cpu baseline: {n} steps in {time.perf_counter() - t0:.1f}s")
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": cores, "kind": kind,
+            "sample": f"{n} greedy decode steps at pos 1..{pos - 1} of the same checkpoint, "
+                      f"OMP_NUM_THREADS={cores}" + (", upstream flags -Ofast" if kind == "reference" else "")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--model", default="4B")
+    ap.add_argument("--context", type=int, default=0, help="cached positions before the timed steps")
+    ap.add_argument("--seq-len", type=int, default=8192, help="context window allocated on the device")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    os.environ["OMP_NUM_THREADS"] = str(host_cores())   # before libgomp is first loaded
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        log(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    ngpu = world
+
+    import numpy as np
+    import q3lib as Q
+    hip = Q.hip_lib()
+    if hip.q3_device_count() <= 0:
+        raise SystemExit("[bench] no HIP device: the product path has no CPU fallback")
+
+    dist = None
+    if ngpu > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")   # control plane only: rendezvous + barriers
+        idb = bytearray(128)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            assert hip.q3_pipeline_unique_id(buf) == 0
+            idb[:] = bytes(buf)
+        t = torch.tensor(list(idb), dtype=torch.uint8)
+        dist.broadcast(t, src=0)
+        raw = bytes(t.tolist())
+        assert hip.q3_pipeline_init(rank, ngpu, raw) == 0
+
+    tmp = Q.tmp_dir()
+    path = os.path.join(tmp, f"{args.model}.bin")
+    t0 = time.perf_counter()
+    if ngpu > 1:
+        if rank == 0:
+            Q.synth(args.model, path)
+        dist.barrier()
+    else:
+        Q.synth(args.model, path)
+    log(f"[bench] checkpoint {path} ready in {time.perf_counter() - t0:.1f}s")
+    seq = max(args.seq_len, args.context + args.steps + args.warmup + 8)
+    m = hip.q3_model_open(path.encode(), seq, 0)
+    assert m, "cannot open checkpoint"
+    p = m.contents.params
+    vocab = p.vocab_size
+    t0 = time.perf_counter()
+    assert hip.q3_device_attach(m) == 0
+    log(f"[bench] weights resident in HBM after {time.perf_counter() - t0:.1f}s")
+
+    K, W = args.steps, args.warmup
+    pos0 = args.context
+    if pos0 > 0:
+        hip.q3_kv_fill_random(m, pos0, 99)
+
+    if ngpu == 1:
+        def run(n, tok, pos):
+            for _ in range(n):
+                lg = hip.forward(m, tok, pos)
+                tok = hip.q3_argmax(lg, vocab)
+                pos += 1
+            return tok, pos
+        tok, pos = run(W, START_TOKEN % vocab, pos0)
+        hip.q3_device_sync(m)
+        t0 = time.perf_counter()
+        tok, pos = run(K, tok, pos)
+        hip.q3_device_sync(m)
+        elapsed = time.perf_counter() - t0
+        total_tokens = K
+    else:
+        hip.q3_pipeline_run.restype = C.c_double
+        hip.q3_pipeline_run.argtypes = [Q.ModelP, C.c_int, C.c_int, C.c_int]
+        hip.q3_pipeline_run(m, START_TOKEN % vocab, pos0, W)
+        dist.barrier()
+        t0 = time.perf_counter()
+        hip.q3_pipeline_run(m, START_TOKEN % vocab, pos0 + W, K)
+        hip.q3_device_sync(m)
+        local = time.perf_counter() - t0
+        import torch
+        tt = torch.tensor([local], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        total_tokens = K * ngpu
+
+    out = {
+        "metric": "decode tokens/sec Qwen3-4B Q8_0" if args.model == "4B" else f"decode tokens/sec Qwen3-{args.model} Q8_0",
+        "value": round(total_tokens / elapsed, 2),
+        "unit": "tokens/s",
+        "n_gpus": ngpu,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": round(1000.0 * elapsed / K, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int8 x int8 -> int32 group dots, fp32 scale-accumulate",
+        "data": "synthetic",
+        "config": {"workload": f"Qwen3-{args.model}-shaped random-init Q8_0 (group 64), single-token decode, "
+                               f"{pos0} cached positions at start, greedy feedback; one forward() per token incl. "
+                               f"D2H of {vocab} logits",
+                   "parallelism": "1 GPU" if ngpu == 1 else f"pp{ngpu}: layer pipeline, RCCL send/recv of the residual, "
+                                                            f"{ngpu} concurrent streams"},
+    }
+    bpt = hip.q3_bytes_per_token(C.byref(p), pos0 + W + K // 2)
+    per_gpu_rate = out["value"] / ngpu
+    out["hbm_roofline_frac_step"] = round(per_gpu_rate * bpt / 1e9 / HBM_PEAK_GBS * (1 if ngpu == 1 else 1.0), 4)
+    out["bytes_per_token"] = int(bpt)
+
+    if rank == 0 and ngpu == 1 and not args.no_roofline:
+        hip.q3_prof_enable(m, 1)
+        hip.q3_prof_reset(m)
+        for _ in range(3):           # untimed: first launches of the non-graph path
+            lg = hip.forward(m, tok, pos); tok = hip.q3_argmax(lg, vocab); pos += 1
+        hip.q3_prof_reset(m)
+        for _ in range(16):
+            lg = hip.forward(m, tok, pos); tok = hip.q3_argmax(lg, vocab); pos += 1
+        ents = (Q.ProfEntry * 16)()
+        n = hip.q3_prof_get(m, ents, 16)
+        hip.q3_prof_enable(m, 0)
+        kern = {}
+        for e in ents[:n]:
+            if e.launches:
+                us = 1000.0 * e.ms_total / e.launches
+                kern[e.name.decode()] = {"launches": int(e.launches), "us": round(us, 3),
+                                         "GBps": round(e.bytes_per_launch / us / 1e3, 1) if e.bytes_per_launch else None}
+        dom = kern.get("gateup")
+        if dom:
+            ach = dom["GBps"]
+            out["roofline"] = {"bound": "hbm", "kernel": "k_gemv<PRO_NORM,EPI_SWIGLU> (gate/up GEMV)",
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "bytes_per_launch": int(hip.q3_gemv_bytes(2 * p.hidden_dim, p.dim)),
+                               "us_per_launch": dom["us"]}
+        out["kernels"] = kern
+    hip.q3_model_close(m)
+
+    if rank == 0 and ngpu == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(path, vocab)
+        except Exception as exc:   # the baseline is a reported number, never a reason to lose the line
+            out["cpu_baseline"] = {"value": None, "error": repr(exc)}
+    if ngpu > 1:
+        hip.q3_pipeline_shutdown()
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+// q3_kernels.hpp -- launch interface between the C-ABI shim and the gfx950 kernels.
+// Every function enqueues on `st` and returns; no allocation, no synchronisation
+// (so the whole step can be captured into a hipGraph).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace q3k {
+
+// control block kept in device memory so that a captured graph never needs
+// its kernel arguments patched: {token, pos}
+struct Ctl {
+    int token;
+    int pos;
+};
+
+enum Pro { PRO_Q8 = 0, PRO_NORM = 1, PRO_F32 = 2 };
+enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
+
+struct Gemv {
+    const int8_t* W;   // [d][n] int8 codes, row-major (reference layout, model.c:131)
+    const float* S;    // [d][n/64] group scales
+    int n, d;
+    // prologue inputs (which are read depends on Pro)
+    const int8_t* xq;  // PRO_Q8: activation codes [n]
+    const float* xs;   // PRO_Q8: activation scales [n/64]
+    const float* xf;   // PRO_NORM / PRO_F32: fp32 activation [n]
+    const float* nw;   // PRO_NORM: RMSNorm weight [n]
+    // epilogue output: EPI_STORE out[d]; EPI_RESID out[d] += ; EPI_SWIGLU out[d/2]
+    float* out;
+};
+
+void gemv(const Gemv& g, Pro pro, Epi epi, hipStream_t st);
+
+struct Attn {
+    const Ctl* ctl;      // pos is read on the device
+    const float* qkv;    // raw projections of this step: q[P] | k[KVD] | v[KVD]
+    const float* qnw;    // per-layer q head-norm weight [hd]
+    const float* knw;    // per-layer k head-norm weight [hd]
+    const float* rope;   // [seq_len][hd/2][2] (cos, sin)
+    float* kc;           // this layer's K cache [n_kv][seq_len][hd]
+    float* vc;           // this layer's V cache [n_kv][seq_len][hd]
+    float* part;         // chunk partials [n_heads][max_chunks][hd+2]
+    int8_t* oq;          // attention output codes [P]
+    float* os;           // attention output scales [P/64]
+    float* of;           // optional fp32 copy of the head outputs [P] (may be null)
+    float* qdbg;         // optional: normed+rotated q [P] (may be null)
+    int n_heads, n_kv, hd, seq_len, max_chunks;
+    int prepared;        // op-level test hook only: q and the k/v of `pos` are already normed + rotated
+};
+// `chunk_slots` workgroups per kv head walk the 64-position chunks of [0,pos];
+// with multi=false the caller guarantees pos < 64 and the kernel finalises itself,
+// otherwise attn_combine() must follow.
+void attn(const Attn& a, int chunk_slots, bool multi, hipStream_t st);
+void attn_combine(const Attn& a, hipStream_t st);
+
+void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, hipStream_t st);
+void argmax(const float* logits, int n, int* out, Ctl* ctl_next, hipStream_t st);
+
+// stand-alone ops behind the reference's exported symbols / the op-level tests
+void rmsnorm(float* out, const float* x, const float* w, int n, hipStream_t st);
+void softmax(float* x, int n, hipStream_t st);
+void quantize(const float* x, int n, int8_t* q, float* s, hipStream_t st);
+void rmsnorm_quantize(const float* x, const float* w, int n, float* normed, int8_t* q, float* s,
+                      hipStream_t st);
+void dequantize(const int8_t* q, const float* s, int n, float* x, hipStream_t st);
+void rope_pairs(float* x, int n_heads, int hd, const float* cs /* [hd/2][2] */, hipStream_t st);
+void headnorm_rope(float* heads, int n_heads, int hd, const float* w, const float* cs, hipStream_t st);
+void swiglu(const float* g, const float* u, int n, float* out, hipStream_t st);
+void expf_map(const float* x, int n, float* out, hipStream_t st);
+void fill_random(float* p, size_t n, uint64_t seed, hipStream_t st);
+
+}  // namespace q3k

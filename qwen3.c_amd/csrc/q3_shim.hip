@@ -1,0 +1,897 @@
+// q3_shim.hip -- the C-ABI of libq3hip.so: the reference's forward.h / q8.h symbols
+// (include/q3_forward.h) and the extension entry points (include/q3_ext.h) on top of
+// the gfx950 kernels in q3_kernels.hip.
+//
+// The reference's Model has no opaque slot for a backend (include/model.h:123-129) and
+// forward() has no handle argument, so the device state of a Model lives in a side
+// registry keyed by the Model pointer; it is created on the first forward() (weights
+// are uploaded from the views the loader carved out of the mmap) and torn down by
+// q3_device_detach()/q3_model_close() or at exit.
+//
+// HBM layout per Model (all hipMalloc'd once at attach, nothing allocated per step):
+//   per layer   qkv  : rows of wq | wk | wv concatenated  [(P+2KVD)][dim] int8 + [..][dim/64] f32
+//               wo   : [dim][P]            gate/up : rows interleaved g0,u0,g1,u1..  [2*HID][dim]
+//               down : [dim][HID]          norms   : att, ffn [dim]; q, k [hd]
+//               K, V : [n_kv][seq_len][hd] f32 (positions of one head contiguous, so one
+//                      1 KiB wave-load is two whole key rows)
+//   embedding / lm_head (shared when tied), final norm, RoPE table [seq_len][hd/2][2]
+//   activations x[dim], qkv[P+2KVD], att codes[P]+scales, h[HID], logits[V], chunk partials
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "q3_ext.h"
+#include "q3_forward.h"
+#include "q3_kernels.hpp"
+#include "q3_numerics.h"
+
+#define Q3_DIE(...)                         \
+    do {                                    \
+        fprintf(stderr, "[q3hip] " __VA_ARGS__); \
+        fprintf(stderr, "\n");              \
+        exit(EXIT_FAILURE);                 \
+    } while (0)
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            Q3_DIE("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+namespace {
+
+struct LayerDev {
+    int8_t *qkv_q, *wo_q, *gu_q, *dn_q;
+    float *qkv_s, *wo_s, *gu_s, *dn_s;
+    float *att_nw, *ffn_nw, *qnw, *knw;
+    float *kc, *vc;
+};
+
+struct ProfSlot {
+    const char* name;
+    double bytes;
+    int64_t launches;
+    double ms;
+};
+
+struct Pipe {
+    bool on = false;
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+};
+Pipe g_pipe;
+
+struct Dev {
+    Model* m = nullptr;
+    int device = 0;
+    hipStream_t st = nullptr;
+    int dim = 0, hid = 0, L = 0, H = 0, KV = 0, hd = 0, P = 0, KVD = 0, V = 0, seq = 0;
+    int l0 = 0, l1 = 0;          // layers [l0, l1) live on this device
+    bool has_embed = true, has_cls = true;
+    std::vector<LayerDev> layers; // indexed by global layer id; only [l0,l1) filled
+    std::vector<void*> allocs;
+    int8_t *emb_q = nullptr, *cls_q = nullptr, *att_q = nullptr;
+    float *emb_s = nullptr, *cls_s = nullptr, *out_nw = nullptr;
+    float *x = nullptr, *qkv = nullptr, *h = nullptr, *logits = nullptr, *att_s = nullptr;
+    float *att_f = nullptr, *part = nullptr, *rope = nullptr, *tap_dev = nullptr;
+    q3k::Ctl* ctl = nullptr;
+    q3k::Ctl* ctl_host = nullptr;
+    int* amax = nullptr;
+    int* amax_host = nullptr;
+    int max_chunks = 1, chunk_slots = 1;
+    bool logits_pinned = false;
+    bool use_graph = true;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] pos < 64, [1] chunked attention
+    bool tap = false;
+    std::vector<float> tap_host;
+    bool prof = false;
+    std::vector<ProfSlot> prof_slots;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_slot;     // slot index of each used pair in this step
+    size_t ev_used = 0;
+};
+
+std::mutex g_mu;
+std::unordered_map<Model*, Dev*> g_reg;
+bool g_atexit = false;
+
+int pick_device() {
+    const char* e = getenv("Q3_DEVICE");
+    if (e && *e) return atoi(e);
+    e = getenv("LOCAL_RANK");
+    if (e && *e) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) == hipSuccess && n > 0) return atoi(e) % n;
+    }
+    return 0;
+}
+
+template <typename T>
+T* dalloc(Dev* d, size_t count) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, count * sizeof(T) + 256));
+    d->allocs.push_back(p);
+    return reinterpret_cast<T*>(p);
+}
+
+template <typename T>
+T* upload(Dev* d, const T* host, size_t count) {
+    T* p = dalloc<T>(d, count);
+    HIPCHK(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return p;
+}
+
+__global__ void k_interleave_rows(char* dst, const char* src, size_t row_bytes, size_t rows, int which) {
+    // dst row 2r+which = src row r; 16-byte units
+    const size_t units = row_bytes / 4;
+    const size_t total = rows * units;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / units, u = i - r * units;
+        reinterpret_cast<int*>(dst)[(2 * r + which) * units + u] = reinterpret_cast<const int*>(src)[i];
+    }
+}
+
+void die_if_no_gpu() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        Q3_DIE("no usable HIP device (%s): this library has no CPU path",
+               e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+}
+
+void build_rope(Dev* d) {
+    // the same libm calls, in the same order, as reference rotary() (forward.c:107-111)
+    const int half = d->hd / 2;
+    std::vector<float> tab((size_t)d->seq * d->hd);
+#pragma omp parallel for schedule(static)
+    for (int pos = 0; pos < d->seq; pos++) {
+        for (int i = 0; i < half; i++) {
+            const float angle = pos * powf(1e6f, -(float)i / half);
+            tab[(size_t)pos * d->hd + 2 * i] = cosf(angle);
+            tab[(size_t)pos * d->hd + 2 * i + 1] = sinf(angle);
+        }
+    }
+    d->rope = upload<float>(d, tab.data(), tab.size());
+}
+
+void upload_weights(Dev* d) {
+    const Model* m = d->m;
+    const ModelWeights* w = &m->weights;
+    const size_t dim = d->dim, P = d->P, KVD = d->KVD, hid = d->hid, V = d->V, hd = d->hd;
+    const size_t G = Q3_GROUP;
+    d->layers.resize(d->L);
+    // staging buffer for the gate/up row interleave
+    char* stage_q = nullptr;
+    char* stage_s = nullptr;
+    HIPCHK(hipMalloc((void**)&stage_q, hid * dim));
+    HIPCHK(hipMalloc((void**)&stage_s, hid * dim / G * 4));
+    for (int l = d->l0; l < d->l1; l++) {
+        LayerDev& L = d->layers[l];
+        const size_t rows = P + 2 * KVD;
+        L.qkv_q = dalloc<int8_t>(d, rows * dim);
+        L.qkv_s = dalloc<float>(d, rows * dim / G);
+        HIPCHK(hipMemcpy(L.qkv_q, w->wq[l].q, P * dim, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(L.qkv_q + P * dim, w->wk[l].q, KVD * dim, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(L.qkv_q + (P + KVD) * dim, w->wv[l].q, KVD * dim, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(L.qkv_s, w->wq[l].s, P * dim / G * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(L.qkv_s + P * dim / G, w->wk[l].s, KVD * dim / G * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(L.qkv_s + (P + KVD) * dim / G, w->wv[l].s, KVD * dim / G * 4, hipMemcpyHostToDevice));
+        L.wo_q = upload<int8_t>(d, w->wo[l].q, dim * P);
+        L.wo_s = upload<float>(d, w->wo[l].s, dim * P / G);
+        L.dn_q = upload<int8_t>(d, w->w2[l].q, dim * hid);
+        L.dn_s = upload<float>(d, w->w2[l].s, dim * hid / G);
+        L.gu_q = dalloc<int8_t>(d, 2 * hid * dim);
+        L.gu_s = dalloc<float>(d, 2 * hid * dim / G);
+        for (int which = 0; which < 2; which++) {
+            const Q8Tensor* src = which == 0 ? &w->w1[l] : &w->w3[l];
+            HIPCHK(hipMemcpy(stage_q, src->q, hid * dim, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(stage_s, src->s, hid * dim / G * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_interleave_rows, dim3(2048), dim3(256), 0, d->st, (char*)L.gu_q, stage_q,
+                               dim, hid, which);
+            hipLaunchKernelGGL(k_interleave_rows, dim3(256), dim3(256), 0, d->st, (char*)L.gu_s, stage_s,
+                               dim / G * 4, hid, which);
+            HIPCHK(hipStreamSynchronize(d->st));
+        }
+        L.att_nw = upload<float>(d, w->att_rms_norm + (size_t)l * dim, dim);
+        L.ffn_nw = upload<float>(d, w->ffn_rms_norm + (size_t)l * dim, dim);
+        L.qnw = upload<float>(d, w->q_rms_norm + (size_t)l * hd, hd);
+        L.knw = upload<float>(d, w->k_rms_norm + (size_t)l * hd, hd);
+        const size_t cache = (size_t)d->KV * d->seq * hd;
+        L.kc = dalloc<float>(d, cache);
+        L.vc = dalloc<float>(d, cache);
+        HIPCHK(hipMemsetAsync(L.kc, 0, cache * 4, d->st));
+        HIPCHK(hipMemsetAsync(L.vc, 0, cache * 4, d->st));
+    }
+    HIPCHK(hipStreamSynchronize(d->st));
+    HIPCHK(hipFree(stage_q));
+    HIPCHK(hipFree(stage_s));
+    const bool tied = m->params.shared_classifier != 0;
+    if (d->has_embed || (tied && d->has_cls)) {
+        d->emb_q = upload<int8_t>(d, w->qe->q, V * dim);
+        d->emb_s = upload<float>(d, w->qe->s, V * dim / G);
+    }
+    if (d->has_cls) {
+        if (tied) {
+            d->cls_q = d->emb_q;
+            d->cls_s = d->emb_s;
+        } else {
+            d->cls_q = upload<int8_t>(d, w->cls->q, V * dim);
+            d->cls_s = upload<float>(d, w->cls->s, V * dim / G);
+        }
+        d->out_nw = upload<float>(d, w->out_rms_norm, dim);
+    }
+}
+
+void pipeline_split(int L, int rank, int world, int* first, int* count) {
+    const int base = L / world, rem = L % world;
+    *count = base + (rank < rem ? 1 : 0);
+    *first = rank * base + (rank < rem ? rank : rem);
+}
+
+Dev* attach(Model* m) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_reg.find(m);
+        if (it != g_reg.end()) return it->second;
+    }
+    die_if_no_gpu();
+    const ModelParams* p = &m->params;
+    if (p->block_size != Q3_GROUP) Q3_DIE("group size %d is not 64", p->block_size);
+    if (p->head_dim != 64 && p->head_dim != 128) Q3_DIE("head_dim %d not supported (64 or 128)", p->head_dim);
+    if (p->dim % 64 || p->hidden_dim % 64) Q3_DIE("dim/hidden_dim must be multiples of 64");
+    Dev* d = new Dev();
+    d->m = m;
+    d->device = pick_device();
+    HIPCHK(hipSetDevice(d->device));
+    HIPCHK(hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking));
+    d->dim = p->dim; d->hid = p->hidden_dim; d->L = p->n_layers; d->H = p->n_heads;
+    d->KV = p->n_kv_heads; d->hd = p->head_dim; d->V = p->vocab_size; d->seq = p->seq_len;
+    d->P = d->H * d->hd; d->KVD = d->KV * d->hd;
+    d->l0 = 0; d->l1 = d->L;
+    if (g_pipe.on) {
+        int first, count;
+        pipeline_split(d->L, g_pipe.rank, g_pipe.world, &first, &count);
+        d->l0 = first; d->l1 = first + count;
+        d->has_embed = g_pipe.rank == 0;
+        d->has_cls = g_pipe.rank == g_pipe.world - 1;
+    }
+    const char* eg = getenv("Q3_GRAPH");
+    d->use_graph = !(eg && eg[0] == '0');
+
+    upload_weights(d);
+    build_rope(d);
+    d->x = dalloc<float>(d, d->dim);
+    d->qkv = dalloc<float>(d, d->P + 2 * d->KVD);
+    d->h = dalloc<float>(d, d->hid);
+    d->logits = dalloc<float>(d, d->V);
+    d->att_q = dalloc<int8_t>(d, d->P);
+    d->att_s = dalloc<float>(d, d->P / 64);
+    d->att_f = dalloc<float>(d, d->P);
+    d->max_chunks = (d->seq + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
+    d->chunk_slots = d->max_chunks < 64 ? d->max_chunks : 64;
+    d->part = dalloc<float>(d, (size_t)d->H * d->max_chunks * (d->hd + 2));
+    d->tap_dev = dalloc<float>(d, (size_t)d->L * d->dim);
+    d->ctl = dalloc<q3k::Ctl>(d, 1);
+    d->amax = dalloc<int>(d, 1);
+    HIPCHK(hipHostMalloc((void**)&d->ctl_host, sizeof(q3k::Ctl), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&d->amax_host, sizeof(int), hipHostMallocDefault));
+    if (m->state.logits) {
+        hipError_t e = hipHostRegister(m->state.logits, (size_t)d->V * sizeof(float), hipHostRegisterDefault);
+        d->logits_pinned = (e == hipSuccess);
+        if (!d->logits_pinned) (void)hipGetLastError();
+    }
+    d->tap_host.assign((size_t)d->L * d->dim, 0.0f);
+    HIPCHK(hipStreamSynchronize(d->st));
+
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_reg[m] = d;
+    if (!g_atexit) {
+        g_atexit = true;
+        atexit([]() {
+            std::vector<Model*> ms;
+            {
+                std::lock_guard<std::mutex> lk2(g_mu);
+                for (auto& kv : g_reg) ms.push_back(kv.first);
+            }
+            for (Model* mm : ms) q3_device_detach(mm);
+        });
+    }
+    return d;
+}
+
+Dev* lookup(Model* m) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_reg.find(m);
+    return it == g_reg.end() ? nullptr : it->second;
+}
+
+// ---- profiling helpers ----------------------------------------------------
+
+int prof_slot(Dev* d, const char* name, double bytes) {
+    for (size_t i = 0; i < d->prof_slots.size(); i++) {
+        if (!strcmp(d->prof_slots[i].name, name)) return (int)i;
+    }
+    d->prof_slots.push_back({name, bytes, 0, 0.0});
+    return (int)d->prof_slots.size() - 1;
+}
+
+struct Timed {
+    Dev* d;
+    bool on;
+    size_t idx;
+    Timed(Dev* dev, const char* name, double bytes) : d(dev), on(dev->prof), idx(0) {
+        if (!on) return;
+        if (d->ev_used == d->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            d->ev_pool.push_back({a, b});
+            d->ev_slot.push_back(0);
+        }
+        idx = d->ev_used++;
+        d->ev_slot[idx] = prof_slot(d, name, bytes);
+        HIPCHK(hipEventRecord(d->ev_pool[idx].first, d->st));
+    }
+    ~Timed() {
+        if (on) HIPCHK(hipEventRecord(d->ev_pool[idx].second, d->st));
+    }
+};
+
+void prof_collect(Dev* d) {
+    if (!d->prof) return;
+    HIPCHK(hipStreamSynchronize(d->st));
+    for (size_t i = 0; i < d->ev_used; i++) {
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, d->ev_pool[i].first, d->ev_pool[i].second));
+        ProfSlot& s = d->prof_slots[d->ev_slot[i]];
+        s.launches++;
+        s.ms += ms;
+    }
+    d->ev_used = 0;
+}
+
+// ---- the decode step --------------------------------------------------------
+
+q3k::Attn attn_args(Dev* d, int l) {
+    const LayerDev& L = d->layers[l];
+    q3k::Attn a;
+    a.ctl = d->ctl; a.qkv = d->qkv; a.qnw = L.qnw; a.knw = L.knw; a.rope = d->rope;
+    a.kc = L.kc; a.vc = L.vc; a.part = d->part; a.oq = d->att_q; a.os = d->att_s;
+    a.of = nullptr; a.qdbg = nullptr; a.prepared = 0;
+    a.n_heads = d->H; a.n_kv = d->KV; a.hd = d->hd; a.seq_len = d->seq; a.max_chunks = d->max_chunks;
+    return a;
+}
+
+void enqueue_layer(Dev* d, int l, bool multi) {
+    const LayerDev& L = d->layers[l];
+    q3k::Gemv g;
+    memset(&g, 0, sizeof(g));
+    {   // rmsnorm + quantise + Wq|Wk|Wv  (reference forward.c:254-262)
+        g.W = L.qkv_q; g.S = L.qkv_s; g.n = d->dim; g.d = d->P + 2 * d->KVD;
+        g.xf = d->x; g.nw = L.att_nw; g.out = d->qkv;
+        Timed t(d, "qkv", q3_gemv_bytes(g.d, g.n));
+        q3k::gemv(g, q3k::PRO_NORM, q3k::EPI_STORE, d->st);
+    }
+    {   // head norms + RoPE + cache append + attention + quantise (forward.c:267-291)
+        q3k::Attn a = attn_args(d, l);
+        Timed t(d, "attn", 0.0);
+        q3k::attn(a, multi ? d->chunk_slots : 1, multi, d->st);
+        if (multi) q3k::attn_combine(a, d->st);
+    }
+    {   // Wo + residual (forward.c:292-298)
+        g.W = L.wo_q; g.S = L.wo_s; g.n = d->P; g.d = d->dim;
+        g.xq = d->att_q; g.xs = d->att_s; g.out = d->x;
+        Timed t(d, "wo", q3_gemv_bytes(g.d, g.n));
+        q3k::gemv(g, q3k::PRO_Q8, q3k::EPI_RESID, d->st);
+    }
+    {   // rmsnorm + quantise + gate/up + SwiGLU (forward.c:303-321)
+        g.W = L.gu_q; g.S = L.gu_s; g.n = d->dim; g.d = 2 * d->hid;
+        g.xf = d->x; g.nw = L.ffn_nw; g.out = d->h;
+        Timed t(d, "gateup", q3_gemv_bytes(g.d, g.n));
+        q3k::gemv(g, q3k::PRO_NORM, q3k::EPI_SWIGLU, d->st);
+    }
+    {   // quantise + down + residual (forward.c:326-338)
+        g.W = L.dn_q; g.S = L.dn_s; g.n = d->hid; g.d = d->dim;
+        g.xf = d->h; g.nw = nullptr; g.out = d->x;
+        Timed t(d, "down", q3_gemv_bytes(g.d, g.n));
+        q3k::gemv(g, q3k::PRO_F32, q3k::EPI_RESID, d->st);
+    }
+    if (d->tap) {
+        HIPCHK(hipMemcpyAsync(d->tap_dev + (size_t)l * d->dim, d->x, (size_t)d->dim * 4,
+                              hipMemcpyDeviceToDevice, d->st));
+    }
+}
+
+void enqueue_head(Dev* d) {
+    q3k::Gemv g;
+    memset(&g, 0, sizeof(g));
+    g.W = d->cls_q; g.S = d->cls_s; g.n = d->dim; g.d = d->V;
+    g.xf = d->x; g.nw = d->out_nw; g.out = d->logits;
+    Timed t(d, "cls", q3_gemv_bytes(g.d, g.n));
+    q3k::gemv(g, q3k::PRO_NORM, q3k::EPI_STORE, d->st);   // forward.c:344-348
+}
+
+// everything of one step that runs on this device, between the ctl upload and the logits
+void enqueue_step(Dev* d, bool multi) {
+    if (d->has_embed) {
+        Timed t(d, "embed", 0.0);
+        q3k::embed(d->ctl, d->emb_q, d->emb_s, d->dim, d->x, d->st);
+    }
+    for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, multi);
+    if (d->has_cls) enqueue_head(d);
+}
+
+void fetch_logits_async(Dev* d) {
+    HIPCHK(hipMemcpyAsync(d->m->state.logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost, d->st));
+}
+
+hipGraphExec_t build_graph(Dev* d, bool multi, bool with_logits) {
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(d->st, hipStreamCaptureModeThreadLocal));
+    HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
+    enqueue_step(d, multi);
+    if (with_logits) fetch_logits_async(d);
+    HIPCHK(hipStreamEndCapture(d->st, &graph));
+    hipGraphExec_t exec = nullptr;
+    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(graph));
+    return exec;
+}
+
+void check_step_args(Dev* d, int token, int pos) {
+    if (pos < 0 || pos >= d->seq) Q3_DIE("position %d outside the context window [0,%d)", pos, d->seq);
+    if (token < 0 || token >= d->V) Q3_DIE("token %d outside the vocabulary [0,%d)", token, d->V);
+}
+
+// run one step; logits stay on the device unless `to_host`
+void run_step(Dev* d, int token, int pos, bool to_host) {
+    check_step_args(d, token, pos);
+    HIPCHK(hipSetDevice(d->device));
+    if (g_pipe.on && g_pipe.world > 1) Q3_DIE("pipeline step must go through q3_pipeline_step");
+    const bool multi = pos >= Q3_ATT_CHUNK;
+    d->ctl_host->token = token;
+    d->ctl_host->pos = pos;
+    const bool pinned_ok = d->logits_pinned;
+    if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
+        hipGraphExec_t& ex = d->gexec[multi ? 1 : 0];
+        if (!ex) ex = build_graph(d, multi, true);
+        HIPCHK(hipGraphLaunch(ex, d->st));
+        if (to_host) HIPCHK(hipStreamSynchronize(d->st));
+        return;
+    }
+    HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
+    enqueue_step(d, multi);
+    if (d->tap) {
+        HIPCHK(hipMemcpyAsync(d->tap_host.data(), d->tap_dev, d->tap_host.size() * 4, hipMemcpyDeviceToHost, d->st));
+    }
+    if (to_host) {
+        if (pinned_ok) {
+            fetch_logits_async(d);
+            HIPCHK(hipStreamSynchronize(d->st));
+        } else {
+            HIPCHK(hipStreamSynchronize(d->st));
+            HIPCHK(hipMemcpy(d->m->state.logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    prof_collect(d);
+}
+
+// ---- context for the stand-alone ops ---------------------------------------
+struct OpsCtx {
+    bool ready = false;
+    hipStream_t st = nullptr;
+};
+OpsCtx g_ops;
+
+hipStream_t ops_stream() {
+    if (!g_ops.ready) {
+        die_if_no_gpu();
+        HIPCHK(hipSetDevice(pick_device()));
+        HIPCHK(hipStreamCreateWithFlags(&g_ops.st, hipStreamNonBlocking));
+        g_ops.ready = true;
+    }
+    return g_ops.st;
+}
+
+struct DBuf {   // RAII device buffer for the op hooks
+    void* p = nullptr;
+    size_t bytes = 0;
+    explicit DBuf(size_t b) : bytes(b) { HIPCHK(hipMalloc(&p, b ? b : 16)); }
+    DBuf(const void* host, size_t b) : bytes(b) {
+        HIPCHK(hipMalloc(&p, b ? b : 16));
+        if (b) HIPCHK(hipMemcpy(p, host, b, hipMemcpyHostToDevice));
+    }
+    ~DBuf() { (void)hipFree(p); }
+    void to_host(void* host, hipStream_t st) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (bytes) HIPCHK(hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost));
+    }
+    template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+void rope_cs_host(int hd, int pos, std::vector<float>& cs) {
+    const int half = hd / 2;
+    cs.resize((size_t)hd);
+    for (int i = 0; i < half; i++) {
+        const float angle = pos * powf(1e6f, -(float)i / half);
+        cs[2 * i] = cosf(angle);
+        cs[2 * i + 1] = sinf(angle);
+    }
+}
+
+}  // namespace
+
+// ============================================================ C ABI =========
+extern "C" {
+
+const char* q3_version(void) { return "q3hip 0.1 (gfx950)"; }
+
+int q3_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int q3_device_attach(Model* m) {
+    if (!m) return -1;
+    attach(m);
+    return 0;
+}
+
+void q3_device_detach(Model* m) {
+    Dev* d = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_reg.find(m);
+        if (it == g_reg.end()) return;
+        d = it->second;
+        g_reg.erase(it);
+    }
+    (void)hipSetDevice(d->device);
+    (void)hipStreamSynchronize(d->st);
+    for (auto& ex : d->gexec) {
+        if (ex) (void)hipGraphExecDestroy(ex);
+    }
+    for (auto& pr : d->ev_pool) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    if (d->logits_pinned) (void)hipHostUnregister(m->state.logits);
+    for (void* p : d->allocs) (void)hipFree(p);
+    (void)hipHostFree(d->ctl_host);
+    (void)hipHostFree(d->amax_host);
+    (void)hipStreamDestroy(d->st);
+    delete d;
+}
+
+void q3_device_sync(Model* m) {
+    Dev* d = lookup(m);
+    if (d) HIPCHK(hipStreamSynchronize(d->st));
+}
+
+float* forward(Model* m, int token, int pos) {
+    if (!m) Q3_DIE("forward: NULL model");
+    Dev* d = attach(m);
+    run_step(d, token, pos, true);
+    return m->state.logits;
+}
+
+void q3_forward_device(Model* m, int token, int pos) {
+    Dev* d = attach(m);
+    run_step(d, token, pos, false);
+}
+
+void q3_logits_fetch(Model* m) {
+    Dev* d = attach(m);
+    HIPCHK(hipStreamSynchronize(d->st));
+    HIPCHK(hipMemcpy(m->state.logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost));
+}
+
+int q3_device_argmax(Model* m) {
+    Dev* d = attach(m);
+    q3k::argmax(d->logits, d->V, d->amax, nullptr, d->st);
+    HIPCHK(hipMemcpyAsync(d->amax_host, d->amax, sizeof(int), hipMemcpyDeviceToHost, d->st));
+    HIPCHK(hipStreamSynchronize(d->st));
+    return *d->amax_host;
+}
+
+int q3_generate_greedy(Model* m, int token, int pos, int n, int* out_tokens) {
+    Dev* d = attach(m);
+    for (int i = 0; i < n; i++) {
+        if (pos + i >= d->seq) return i;
+        run_step(d, token, pos + i, i == n - 1);
+        token = q3_device_argmax(m);
+        if (out_tokens) out_tokens[i] = token;
+    }
+    return n;
+}
+
+void q3_kv_fill_random(Model* m, int T, uint64_t seed) {
+    Dev* d = attach(m);
+    if (T > d->seq) T = d->seq;
+    for (int l = d->l0; l < d->l1; l++) {
+        for (int g = 0; g < d->KV; g++) {
+            const size_t off = (size_t)g * d->seq * d->hd;
+            q3k::fill_random(d->layers[l].kc + off, (size_t)T * d->hd, seed + 2 * (l * 64 + g), d->st);
+            q3k::fill_random(d->layers[l].vc + off, (size_t)T * d->hd, seed + 2 * (l * 64 + g) + 1, d->st);
+        }
+    }
+    HIPCHK(hipStreamSynchronize(d->st));
+}
+
+void q3_tap_enable(Model* m, int on) {
+    Dev* d = attach(m);
+    d->tap = on != 0;
+}
+
+const float* q3_tap_data(Model* m) {
+    Dev* d = attach(m);
+    return d->tap_host.data();
+}
+
+void q3_layer_step(Model* m, int layer, int pos, const float* x_in, float* x_out) {
+    Dev* d = attach(m);
+    if (layer < d->l0 || layer >= d->l1) Q3_DIE("layer %d is not on this device", layer);
+    check_step_args(d, 0, pos);
+    d->ctl_host->token = 0;
+    d->ctl_host->pos = pos;
+    HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
+    HIPCHK(hipMemcpyAsync(d->x, x_in, (size_t)d->dim * 4, hipMemcpyHostToDevice, d->st));
+    enqueue_layer(d, layer, pos >= Q3_ATT_CHUNK);
+    HIPCHK(hipStreamSynchronize(d->st));
+    HIPCHK(hipMemcpy(x_out, d->x, (size_t)d->dim * 4, hipMemcpyDeviceToHost));
+    prof_collect(d);
+}
+
+void q3_prof_enable(Model* m, int on) {
+    Dev* d = attach(m);
+    d->prof = on != 0;
+}
+
+void q3_prof_reset(Model* m) {
+    Dev* d = attach(m);
+    for (auto& s : d->prof_slots) {
+        s.launches = 0;
+        s.ms = 0.0;
+    }
+}
+
+int q3_prof_get(Model* m, Q3ProfEntry* out, int max_entries) {
+    Dev* d = attach(m);
+    int n = 0;
+    for (auto& s : d->prof_slots) {
+        if (n >= max_entries) break;
+        out[n].name = s.name;
+        out[n].launches = s.launches;
+        out[n].ms_total = s.ms;
+        out[n].bytes_per_launch = s.bytes;
+        n++;
+    }
+    return n;
+}
+
+// ---- reference symbols on host pointers -------------------------------------
+
+void rmsnorm(float* out, float* x, float* w, int size) {
+    hipStream_t st = ops_stream();
+    DBuf dx(x, (size_t)size * 4), dw(w, (size_t)size * 4), dout((size_t)size * 4);
+    q3k::rmsnorm(dout.as<float>(), dx.as<float>(), dw.as<float>(), size, st);
+    dout.to_host(out, st);
+}
+
+void softmax(float* x, int size) {
+    hipStream_t st = ops_stream();
+    DBuf dx(x, (size_t)size * 4);
+    q3k::softmax(dx.as<float>(), size, st);
+    dx.to_host(x, st);
+}
+
+void matmul(float* out, Q8Tensor* x, Q8Tensor* w, int n, int d, int block_size) {
+    if (block_size != Q3_GROUP) Q3_DIE("matmul: group size %d is not 64", block_size);
+    q3_op_gemv(w->q, w->s, x->q, x->s, n, d, out);
+}
+
+void rotary(float* x, int head_dim, int pos) {
+    hipStream_t st = ops_stream();
+    std::vector<float> cs;
+    rope_cs_host(head_dim, pos, cs);
+    DBuf dx(x, (size_t)head_dim * 4), dcs(cs.data(), cs.size() * 4);
+    q3k::rope_pairs(dx.as<float>(), 1, head_dim, dcs.as<float>(), st);
+    dx.to_host(x, st);
+}
+
+// scalar helpers: the same q3_expf the kernels use (q3_numerics.h), evaluated in place
+float sigmoid(float x) { return 1.0f / (1.0f + q3_expf(-x)); }
+float silu(float x) { return x * sigmoid(x); }
+
+void swiglu(float* x1, float* x3, int size) {
+    hipStream_t st = ops_stream();
+    DBuf d1(x1, (size_t)size * 4), d3(x3, (size_t)size * 4);
+    q3k::swiglu(d1.as<float>(), d3.as<float>(), size, d1.as<float>(), st);
+    d1.to_host(x1, st);
+}
+
+void attention(Model* m, int layer, int pos) {
+    Dev* d = attach(m);
+    if (layer < d->l0 || layer >= d->l1) Q3_DIE("layer %d is not on this device", layer);
+    check_step_args(d, 0, pos);
+    d->ctl_host->token = 0;
+    d->ctl_host->pos = pos;
+    HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
+    q3k::Attn a = attn_args(d, layer);
+    a.of = d->att_f;
+    const bool multi = pos >= Q3_ATT_CHUNK;
+    q3k::attn(a, multi ? d->chunk_slots : 1, multi, d->st);
+    if (multi) q3k::attn_combine(a, d->st);
+    HIPCHK(hipStreamSynchronize(d->st));
+    if (m->state.x_rms_norm) {
+        HIPCHK(hipMemcpy(m->state.x_rms_norm, d->att_f, (size_t)d->P * 4, hipMemcpyDeviceToHost));
+    }
+}
+
+void q8_quantize(Q8Tensor* qt, float* x, int n, int block_size) {
+    if (block_size != Q3_GROUP) Q3_DIE("q8_quantize: group size %d is not 64", block_size);
+    q3_op_quantize(x, n, qt->q, qt->s);
+}
+
+void q8_dequantize(Q8Tensor* qt, float* x, int n, int block_size) {
+    if (block_size != Q3_GROUP) Q3_DIE("q8_dequantize: group size %d is not 64", block_size);
+    hipStream_t st = ops_stream();
+    DBuf dq(qt->q, (size_t)n), ds(qt->s, (size_t)n / 64 * 4), dx((size_t)n * 4);
+    q3k::dequantize(dq.as<int8_t>(), ds.as<float>(), n, dx.as<float>(), st);
+    dx.to_host(x, st);
+}
+
+// ---- op-level hooks ------------------------------------------------------------
+
+void q3_op_quantize(const float* x, int n, int8_t* q, float* s) {
+    hipStream_t st = ops_stream();
+    DBuf dx(x, (size_t)n * 4), dq((size_t)n), ds((size_t)n / 64 * 4);
+    q3k::quantize(dx.as<float>(), n, dq.as<int8_t>(), ds.as<float>(), st);
+    dq.to_host(q, st);
+    ds.to_host(s, st);
+}
+
+void q3_op_rmsnorm_quantize(const float* x, const float* w, int n, float* normed, int8_t* q, float* s) {
+    hipStream_t st = ops_stream();
+    DBuf dx(x, (size_t)n * 4), dw(w, (size_t)n * 4), dn((size_t)n * 4), dq((size_t)n), ds((size_t)n / 64 * 4);
+    q3k::rmsnorm_quantize(dx.as<float>(), dw.as<float>(), n, dn.as<float>(), dq.as<int8_t>(), ds.as<float>(), st);
+    dn.to_host(normed, st);
+    dq.to_host(q, st);
+    ds.to_host(s, st);
+}
+
+void q3_op_gemv(const int8_t* wq, const float* ws, const int8_t* xq, const float* xs, int n, int d, float* out) {
+    if (n % 64 || d % 2) Q3_DIE("gemv: n must be a multiple of 64 and d even (n=%d d=%d)", n, d);
+    hipStream_t st = ops_stream();
+    DBuf dw(wq, (size_t)n * d), dws(ws, (size_t)n * d / 64 * 4), dx(xq, (size_t)n), dxs(xs, (size_t)n / 64 * 4);
+    DBuf dout((size_t)d * 4);
+    q3k::Gemv g;
+    memset(&g, 0, sizeof(g));
+    g.W = dw.as<int8_t>(); g.S = dws.as<float>(); g.n = n; g.d = d;
+    g.xq = dx.as<int8_t>(); g.xs = dxs.as<float>(); g.out = dout.as<float>();
+    q3k::gemv(g, q3k::PRO_Q8, q3k::EPI_STORE, st);
+    dout.to_host(out, st);
+}
+
+void q3_op_headnorm_rope(float* heads, int n_heads, int head_dim, const float* w, int pos) {
+    hipStream_t st = ops_stream();
+    std::vector<float> cs;
+    rope_cs_host(head_dim, pos, cs);
+    DBuf dh(heads, (size_t)n_heads * head_dim * 4), dw(w, (size_t)head_dim * 4), dcs(cs.data(), cs.size() * 4);
+    q3k::headnorm_rope(dh.as<float>(), n_heads, head_dim, dw.as<float>(), dcs.as<float>(), st);
+    dh.to_host(heads, st);
+}
+
+void q3_op_attention(const float* q, const float* kcache, const float* vcache, int T, int n_heads,
+                     int n_kv_heads, int head_dim, float* out) {
+    // Runs the production attention kernel in its `prepared` mode: q and the k/v of the
+    // last position are taken as given (already normed + rotated), the cache holds 0..T-2.
+    hipStream_t st = ops_stream();
+    if (T < 1) Q3_DIE("attention: T must be >= 1");
+    const int hd = head_dim, P = n_heads * hd, KVD = n_kv_heads * hd;
+    const int seq = T;
+    // cache in device layout [n_kv][seq][hd]
+    std::vector<float> kc((size_t)KVD * seq), vc((size_t)KVD * seq);
+    for (int t = 0; t < T; t++) {
+        for (int g = 0; g < n_kv_heads; g++) {
+            memcpy(&kc[((size_t)g * seq + t) * hd], kcache + ((size_t)t * n_kv_heads + g) * hd, (size_t)hd * 4);
+            memcpy(&vc[((size_t)g * seq + t) * hd], vcache + ((size_t)t * n_kv_heads + g) * hd, (size_t)hd * 4);
+        }
+    }
+    std::vector<float> qkv((size_t)P + 2 * KVD);
+    memcpy(qkv.data(), q, (size_t)P * 4);
+    memcpy(qkv.data() + P, kcache + (size_t)(T - 1) * KVD, (size_t)KVD * 4);
+    memcpy(qkv.data() + P + KVD, vcache + (size_t)(T - 1) * KVD, (size_t)KVD * 4);
+    const int max_chunks = (T + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
+    DBuf dqkv(qkv.data(), qkv.size() * 4), dkc(kc.data(), kc.size() * 4), dvc(vc.data(), vc.size() * 4);
+    DBuf dpart((size_t)n_heads * max_chunks * (hd + 2) * 4), doq((size_t)P), dos((size_t)P / 64 * 4 + 16);
+    DBuf dof((size_t)P * 4);
+    q3k::Ctl ctl = {0, T - 1};
+    DBuf dctl(&ctl, sizeof(ctl));
+    q3k::Attn a;
+    memset(&a, 0, sizeof(a));
+    a.ctl = dctl.as<q3k::Ctl>(); a.qkv = dqkv.as<float>(); a.qnw = nullptr; a.knw = nullptr; a.rope = nullptr;
+    a.kc = dkc.as<float>(); a.vc = dvc.as<float>(); a.part = dpart.as<float>();
+    a.oq = doq.as<int8_t>(); a.os = dos.as<float>(); a.of = dof.as<float>(); a.qdbg = nullptr;
+    a.n_heads = n_heads; a.n_kv = n_kv_heads; a.hd = hd; a.seq_len = seq; a.max_chunks = max_chunks;
+    a.prepared = 1;
+    const bool multi = T > Q3_ATT_CHUNK;
+    q3k::attn(a, multi ? (max_chunks < 64 ? max_chunks : 64) : 1, multi, st);
+    if (multi) q3k::attn_combine(a, st);
+    dof.to_host(out, st);
+}
+
+void q3_op_swiglu(const float* gate, const float* up, int n, float* out) {
+    hipStream_t st = ops_stream();
+    DBuf dg(gate, (size_t)n * 4), du(up, (size_t)n * 4), dout((size_t)n * 4);
+    q3k::swiglu(dg.as<float>(), du.as<float>(), n, dout.as<float>(), st);
+    dout.to_host(out, st);
+}
+
+void q3_op_expf(const float* x, int n, float* out) {
+    hipStream_t st = ops_stream();
+    DBuf dx(x, (size_t)n * 4), dout((size_t)n * 4);
+    q3k::expf_map(dx.as<float>(), n, dout.as<float>(), st);
+    dout.to_host(out, st);
+}
+
+// ---- pipeline (filled in by q3_pipeline.hip-style code below) --------------------
+
+void q3_pipeline_layers(const ModelParams* p, int rank, int world, int* first, int* count) {
+    pipeline_split(p->n_layers, rank, world, first, count);
+}
+
+int q3_pipeline_unique_id(void* id_bytes) {
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
+    memset(id_bytes, 0, Q3_PIPE_ID_BYTES);
+    memcpy(id_bytes, &id, sizeof(id) < Q3_PIPE_ID_BYTES ? sizeof(id) : Q3_PIPE_ID_BYTES);
+    return 0;
+}
+
+int q3_pipeline_init(int rank, int world, const void* id_bytes) {
+    die_if_no_gpu();
+    if (world < 1 || rank < 0 || rank >= world) return -1;
+    HIPCHK(hipSetDevice(pick_device()));
+    g_pipe.rank = rank;
+    g_pipe.world = world;
+    g_pipe.on = world > 1;
+    if (world > 1) {
+        ncclUniqueId id;
+        memcpy(&id, id_bytes, sizeof(id));
+        ncclResult_t r = ncclCommInitRank(&g_pipe.comm, world, id, rank);
+        if (r != ncclSuccess) {
+            fprintf(stderr, "[q3hip] ncclCommInitRank failed: %s\n", ncclGetErrorString(r));
+            return -1;
+        }
+    }
+    return 0;
+}
+
+void q3_pipeline_shutdown(void) {
+    if (g_pipe.comm) {
+        ncclCommDestroy(g_pipe.comm);
+        g_pipe.comm = nullptr;
+    }
+    g_pipe.on = false;
+    g_pipe.world = 1;
+    g_pipe.rank = 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+"""End-to-end and layer-level parity of forward() on the GPU (SURVEY.md 8(c') tiers B-D)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import q3lib as Q
+
+pytestmark = pytest.mark.gpu
+
+
+def open_pair(hip, host, name, seq=0):
+    path = os.path.join(Q.tmp_dir(), f"{name}.bin")
+    Q.synth(name, path)
+    mg = hip.q3_model_open(path.encode(), seq, 0)
+    mo = host.q3_model_open(path.encode(), seq, 1)
+    assert mg and mo
+    return mg, mo
+
+
+def run_stream(step, n, first=7):
+    tok, toks, logits = first, [], []
+    for pos in range(n):
+        lg = step(tok, pos)
+        logits.append(lg)
+        tok = int(lg.argmax())
+        toks.append(tok)
+    return toks, logits
+
+
+@pytest.mark.parametrize("name,steps", [("tiny", 64), ("small", 140)])
+def test_forward_matches_tree_oracle_bit_exact(hip, host, orc, name, steps):
+    mg, mo = open_pair(hip, host, name)
+    orc.orc_set_mode(Q.ORC_TREE)
+    tg, lg = run_stream(lambda t, p: Q.logits_array(mg, hip.forward(mg, t, p)), steps)
+    to, lo = run_stream(lambda t, p: Q.logits_array(mo, orc.orc_forward(mo, t, p)), steps)
+    assert tg == to
+    for pos in range(steps):
+        assert np.array_equal(lg[pos], lo[pos]), f"pos {pos}"
+    hip.q3_model_close(mg); host.q3_model_close(mo)
+
+
+def test_forward_vs_reference_order_tiny(hip, host, orc):
+    """Tier C: on the tiny fixture no int8 code flips, so the GPU agrees with the
+    reference's own order to 1e-5 of max|logit| and picks the same greedy tokens."""
+    mg, mo = open_pair(hip, host, "tiny")
+    orc.orc_set_mode(Q.ORC_REF)
+    tg, lg = run_stream(lambda t, p: Q.logits_array(mg, hip.forward(mg, t, p)), 64)
+    to, lo = run_stream(lambda t, p: Q.logits_array(mo, orc.orc_forward(mo, t, p)), 64)
+    assert tg == to
+    worst = max(float(np.abs(a - b).max() / np.abs(b).max()) for a, b in zip(lg, lo))
+    assert worst <= 1e-5, worst
+    hip.q3_model_close(mg); host.q3_model_close(mo)
+
+
+def test_graph_and_eager_agree_and_rewind(hip, host):
+    """hipGraph replay == plain launches; and callers may rewind pos to 0 without
+    clearing the cache (reference completion.c:281-284)."""
+    mg, _mo = open_pair(hip, host, "small")
+    a_t, a_l = run_stream(lambda t, p: Q.logits_array(mg, hip.forward(mg, t, p)), 80)
+    b_t, b_l = run_stream(lambda t, p: Q.logits_array(mg, hip.forward(mg, t, p)), 80)   # rewound
+    assert a_t == b_t and all(np.array_equal(x, y) for x, y in zip(a_l, b_l))
+    hip.q3_tap_enable(mg, 1)     # the tap forces plain launches
+    c_t, c_l = run_stream(lambda t, p: Q.logits_array(mg, hip.forward(mg, t, p)), 80)
+    hip.q3_tap_enable(mg, 0)
+    assert a_t == c_t and all(np.array_equal(x, y) for x, y in zip(a_l, c_l))
+    hip.q3_model_close(mg); host.q3_model_close(_mo)
+
+
+def test_layer_taps_and_teacher_forced_layers(hip, host, orc):
+    mg, mo = open_pair(hip, host, "small")
+    p = mg.contents.params
+    L, dim = p.n_layers, p.dim
+    orc.orc_set_mode(Q.ORC_TREE)
+    tap = np.zeros(L * dim, np.float32)
+    orc.orc_set_tap(Q.fptr(tap))
+    hip.q3_tap_enable(mg, 1)
+    tok = 11
+    for pos in range(70):
+        lo = Q.logits_array(mo, orc.orc_forward(mo, tok, pos))
+        lg = Q.logits_array(mg, hip.forward(mg, tok, pos))
+        gt = np.ctypeslib.as_array(hip.q3_tap_data(mg), shape=(L * dim,))
+        assert np.array_equal(gt, tap), f"pos {pos}"
+        assert np.array_equal(lg, lo)
+        tok = int(lo.argmax())
+    orc.orc_set_tap(None)
+    hip.q3_tap_enable(mg, 0)
+    # tier B: one layer from the oracle's (reference-order) residual
+    orc.orc_set_mode(Q.ORC_REF)
+    rng = np.random.default_rng(3)
+    for layer in range(L):
+        x = rng.standard_normal(dim).astype(np.float32)
+        xo = np.zeros(dim, np.float32); xg = np.zeros(dim, np.float32)
+        orc.orc_layer_step(mo, layer, 70, Q.fptr(x), Q.fptr(xo))
+        hip.q3_layer_step(mg, layer, 70, Q.fptr(x), Q.fptr(xg))
+        assert float(np.abs(xg - xo).max() / np.abs(xo).max()) <= 1e-3
+    hip.q3_model_close(mg); host.q3_model_close(mo)
+
+
+def test_device_argmax_and_greedy_loop(hip, host):
+    mg, _mo = open_pair(hip, host, "small")
+    toks, _ = run_stream(lambda t, p: Q.logits_array(mg, hip.forward(mg, t, p)), 20)
+    out = (C.c_int * 20)()
+    assert hip.q3_generate_greedy(mg, 7, 0, 20, out) == 20
+    assert list(out) == toks
+    hip.q3_model_close(mg); host.q3_model_close(_mo)
