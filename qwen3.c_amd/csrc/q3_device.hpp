@@ -1,0 +1,172 @@
+// q3_device.hpp -- wave64 building blocks shared by the gfx950 kernels.
+// Arithmetic contract: q3_numerics.h.  All cross-lane traffic uses the cheapest
+// gfx950 instruction that realises the contract's pairing:
+//   xor 1, 2      DPP quad_perm (no LDS hardware involved)
+//   xor 4, 8, 16  ds_swizzle_b32 in bit-mask mode (LDS crossbar, no address VGPR)
+//   xor 32        v_permlane32_swap
+// (hipcc lowers __shfl_xor to ds_bpermute_b32 with a computed address for all of them.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "q3_numerics.h"
+
+namespace q3k {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+template <int M>
+__device__ __forceinline__ int lane_xor_i(int v) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "xor mask");
+    if constexpr (M == 1) {
+        return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    } else if constexpr (M == 2) {
+        return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    } else if constexpr (M == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        return (int)((threadIdx.x & 32) ? r[0] : r[1]);
+    } else {
+        return __builtin_amdgcn_ds_swizzle(v, (M << 10) | 0x1F);
+    }
+}
+template <int M>
+__device__ __forceinline__ float lane_xor_f(float v) {
+    return __int_as_float(lane_xor_i<M>(__float_as_int(v)));
+}
+
+// butterfly over the 64 lanes of a wave: xor 32,16,8,4,2,1
+__device__ __forceinline__ float bfly64(float v) {
+    v = v + lane_xor_f<32>(v);
+    v = v + lane_xor_f<16>(v);
+    v = v + lane_xor_f<8>(v);
+    v = v + lane_xor_f<4>(v);
+    v = v + lane_xor_f<2>(v);
+    v = v + lane_xor_f<1>(v);
+    return v;
+}
+// butterfly inside each 32-lane half: xor 16,8,4,2,1
+__device__ __forceinline__ float bfly32(float v) {
+    v = v + lane_xor_f<16>(v);
+    v = v + lane_xor_f<8>(v);
+    v = v + lane_xor_f<4>(v);
+    v = v + lane_xor_f<2>(v);
+    v = v + lane_xor_f<1>(v);
+    return v;
+}
+// SUM16 butterfly over the 16 quads of a wave (all 4 lanes of a quad hold the same
+// value): xor 8,4,2,1 on the quad index = xor 32,16,8,4 on the lane
+__device__ __forceinline__ float bfly_quads(float v) {
+    v = v + lane_xor_f<32>(v);
+    v = v + lane_xor_f<16>(v);
+    v = v + lane_xor_f<8>(v);
+    v = v + lane_xor_f<4>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, lane_xor_f<32>(v));
+    v = fmaxf(v, lane_xor_f<16>(v));
+    v = fmaxf(v, lane_xor_f<8>(v));
+    v = fmaxf(v, lane_xor_f<4>(v));
+    v = fmaxf(v, lane_xor_f<2>(v));
+    v = fmaxf(v, lane_xor_f<1>(v));
+    return v;
+}
+
+// SUM256 of x_i^2 over n floats (n % 4 == 0), computed by ONE wave.
+__device__ __forceinline__ float sum256_sq(const float* __restrict__ x, int n, int lane) {
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int i = 4 * lane; i < n; i += 256) {
+        const float4 v = x4[i >> 2];
+        c0 = c0 + v.x * v.x;
+        c1 = c1 + v.y * v.y;
+        c2 = c2 + v.z * v.z;
+        c3 = c3 + v.w * v.w;
+    }
+    return bfly64((c0 + c1) + (c2 + c3));
+}
+
+// q8_quantize (reference src/q8.c:5-30) of one 64-wide group held by 16 consecutive
+// lanes, four consecutive values each.  Returns the 4 packed codes; `scale` gets the
+// group scale in every lane of the group.
+__device__ __forceinline__ int quantize_group16(float4 y, float& scale) {
+    float amax = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
+    amax = fmaxf(amax, lane_xor_f<1>(amax));
+    amax = fmaxf(amax, lane_xor_f<2>(amax));
+    amax = fmaxf(amax, lane_xor_f<4>(amax));
+    amax = fmaxf(amax, lane_xor_f<8>(amax));
+    scale = q3_q8_scale(amax);
+    const int q0 = (int)fminf(fmaxf(roundf(y.x / scale), -127.0f), 127.0f);
+    const int q1 = (int)fminf(fmaxf(roundf(y.y / scale), -127.0f), 127.0f);
+    const int q2 = (int)fminf(fmaxf(roundf(y.z / scale), -127.0f), 127.0f);
+    const int q3 = (int)fminf(fmaxf(roundf(y.w / scale), -127.0f), 127.0f);
+    return (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+}
+
+__device__ __forceinline__ int dot16(v4i w, v4i x) {
+    int d = __builtin_amdgcn_sdot4(w.x, x.x, 0, false);
+    d = __builtin_amdgcn_sdot4(w.y, x.y, d, false);
+    d = __builtin_amdgcn_sdot4(w.z, x.z, d, false);
+    d = __builtin_amdgcn_sdot4(w.w, x.w, d, false);
+    return d;
+}
+// exact int32 sum over the 4 lanes of a quad
+__device__ __forceinline__ int quad_sum(int d) {
+    d += lane_xor_i<1>(d);
+    d += lane_xor_i<2>(d);
+    return d;
+}
+
+// RMSNorm (size HD, weight w) + half-split RoPE of one head held as float4 per lane in
+// lanes [0, HD/4) of a wave (reference forward.c:270-280, 104-118).
+// cs = (cos,sin) pairs of this position, [HD/2][2].
+template <int HD>
+__device__ __forceinline__ float4 headnorm_rope_wave(float4 v, const float* __restrict__ w,
+                                                     const float* __restrict__ cs, int lane) {
+    constexpr int L4 = HD / 4;
+    const bool act = lane < L4;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    if (act) {
+        c0 = c0 + v.x * v.x;
+        c1 = c1 + v.y * v.y;
+        c2 = c2 + v.z * v.z;
+        c3 = c3 + v.w * v.w;
+    }
+    const float ss = bfly64((c0 + c1) + (c2 + c3));
+    const float s = 1.0f / sqrtf(ss / (float)HD + 1e-6f);
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+        const float4 g = *reinterpret_cast<const float4*>(w + 4 * lane);
+        y.x = g.x * (s * v.x);
+        y.y = g.y * (s * v.y);
+        y.z = g.z * (s * v.z);
+        y.w = g.w * (s * v.w);
+    }
+    // element i < HD/2 pairs with i + HD/2: partner lane = lane ^ (L4/2)
+    float4 o;
+    o.x = lane_xor_f<L4 / 2>(y.x);
+    o.y = lane_xor_f<L4 / 2>(y.y);
+    o.z = lane_xor_f<L4 / 2>(y.z);
+    o.w = lane_xor_f<L4 / 2>(y.w);
+    float4 r = y;
+    if (act) {
+        const bool lo = lane < L4 / 2;
+        const int i0 = 4 * (lo ? lane : lane - L4 / 2);
+        const float4 ca = *reinterpret_cast<const float4*>(cs + 2 * i0);      // c0 s0 c1 s1
+        const float4 cb = *reinterpret_cast<const float4*>(cs + 2 * i0 + 4);  // c2 s2 c3 s3
+        if (lo) {   // own = real, other = imag: real*cos - imag*sin
+            r.x = y.x * ca.x - o.x * ca.y;
+            r.y = y.y * ca.z - o.y * ca.w;
+            r.z = y.z * cb.x - o.z * cb.y;
+            r.w = y.w * cb.z - o.w * cb.w;
+        } else {    // own = imag, other = real: real*sin + imag*cos
+            r.x = o.x * ca.y + y.x * ca.x;
+            r.y = o.y * ca.w + y.y * ca.z;
+            r.z = o.z * cb.y + y.z * cb.x;
+            r.w = o.w * cb.w + y.w * cb.z;
+        }
+    }
+    return r;
+}
+
+}  // namespace q3k

@@ -27,71 +27,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "q3_device.hpp"
 #include "q3_numerics.h"
 
 namespace q3k {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-#define Q3_WAVE 64
-
-__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, Q3_WAVE); }
-__device__ __forceinline__ int shfl_xor_i(int v, int m) { return __shfl_xor(v, m, Q3_WAVE); }
-
-// butterfly over the 64 lanes of a wave: xor 32,16,8,4,2,1 (q3_numerics.h)
-__device__ __forceinline__ float bfly64(float v) {
-    v = v + shfl_xor_f(v, 32);
-    v = v + shfl_xor_f(v, 16);
-    v = v + shfl_xor_f(v, 8);
-    v = v + shfl_xor_f(v, 4);
-    v = v + shfl_xor_f(v, 2);
-    v = v + shfl_xor_f(v, 1);
-    return v;
-}
-// butterfly inside each 32-lane half: xor 16,8,4,2,1
-__device__ __forceinline__ float bfly32(float v) {
-    v = v + shfl_xor_f(v, 16);
-    v = v + shfl_xor_f(v, 8);
-    v = v + shfl_xor_f(v, 4);
-    v = v + shfl_xor_f(v, 2);
-    v = v + shfl_xor_f(v, 1);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor_f(v, m));
-    return v;
-}
-
-// SUM256 of x_i^2 over a vector of n floats (n % 4 == 0), computed by ONE wave.
-__device__ __forceinline__ float sum256_sq(const float* __restrict__ x, int n, int lane) {
-    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    for (int i = 4 * lane; i < n; i += 256) {
-        const float4 v = x4[i >> 2];
-        c0 = c0 + v.x * v.x;
-        c1 = c1 + v.y * v.y;
-        c2 = c2 + v.z * v.z;
-        c3 = c3 + v.w * v.w;
-    }
-    return bfly64((c0 + c1) + (c2 + c3));
-}
-
-// q8_quantize (reference src/q8.c:5-30) of one 64-wide group held by 16
-// consecutive lanes, four consecutive values each.  Returns the 4 packed codes;
-// `scale` gets the group scale in every lane of the group.
-__device__ __forceinline__ int quantize_group16(float4 y, float& scale) {
-    float amax = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
-    amax = fmaxf(amax, shfl_xor_f(amax, 1));
-    amax = fmaxf(amax, shfl_xor_f(amax, 2));
-    amax = fmaxf(amax, shfl_xor_f(amax, 4));
-    amax = fmaxf(amax, shfl_xor_f(amax, 8));
-    scale = q3_q8_scale(amax);
-    const int q0 = (int)fminf(fmaxf(roundf(y.x / scale), -127.0f), 127.0f);
-    const int q1 = (int)fminf(fmaxf(roundf(y.y / scale), -127.0f), 127.0f);
-    const int q2 = (int)fminf(fmaxf(roundf(y.z / scale), -127.0f), 127.0f);
-    const int q3 = (int)fminf(fmaxf(roundf(y.w / scale), -127.0f), 127.0f);
-    return (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
-}
 
 // ---------------------------------------------------------------- GEMV -----
 
@@ -138,14 +77,6 @@ __device__ __forceinline__ void stage_quantize(const float* __restrict__ x, cons
             if (normed) *reinterpret_cast<float4*>(normed + i) = y;
         }
     }
-}
-
-__device__ __forceinline__ int dot16(v4i w, v4i x) {
-    int d = __builtin_amdgcn_sdot4(w.x, x.x, 0, false);
-    d = __builtin_amdgcn_sdot4(w.y, x.y, d, false);
-    d = __builtin_amdgcn_sdot4(w.z, x.z, d, false);
-    d = __builtin_amdgcn_sdot4(w.w, x.w, d, false);
-    return d;
 }
 
 // NJ = number of 1 KiB wave-loads per row (compile-time when > 0, else runtime).
@@ -196,24 +127,24 @@ __global__ __launch_bounds__(NT) void k_gemv(Gemv a) {
             }
             int da = dot16(wa, xv);
             int db = dot16(wb, xv);
-            da += shfl_xor_i(da, 1);
-            db += shfl_xor_i(db, 1);
-            da += shfl_xor_i(da, 2);
-            db += shfl_xor_i(db, 2);
+            da += lane_xor_i<1>(da);
+            db += lane_xor_i<1>(db);
+            da += lane_xor_i<2>(da);
+            db += lane_xor_i<2>(db);
             const float pa = ((float)da * sa) * sx;
             const float pb = ((float)db * sb) * sx;
             acc0 = act ? acc0 + pa : acc0;
             acc1 = act ? acc1 + pb : acc1;
         }
         // SUM16 butterfly over the 16 quads (column c = lane/4): xor 8,4,2,1 on c
-        acc0 = acc0 + shfl_xor_f(acc0, 32);
-        acc1 = acc1 + shfl_xor_f(acc1, 32);
-        acc0 = acc0 + shfl_xor_f(acc0, 16);
-        acc1 = acc1 + shfl_xor_f(acc1, 16);
-        acc0 = acc0 + shfl_xor_f(acc0, 8);
-        acc1 = acc1 + shfl_xor_f(acc1, 8);
-        acc0 = acc0 + shfl_xor_f(acc0, 4);
-        acc1 = acc1 + shfl_xor_f(acc1, 4);
+        acc0 = acc0 + lane_xor_f<32>(acc0);
+        acc1 = acc1 + lane_xor_f<32>(acc1);
+        acc0 = acc0 + lane_xor_f<16>(acc0);
+        acc1 = acc1 + lane_xor_f<16>(acc1);
+        acc0 = acc0 + lane_xor_f<8>(acc0);
+        acc1 = acc1 + lane_xor_f<8>(acc1);
+        acc0 = acc0 + lane_xor_f<4>(acc0);
+        acc1 = acc1 + lane_xor_f<4>(acc1);
         if (lane == 0) {
             if (EPI == EPI_STORE) {
                 a.out[row0] = acc0;
@@ -252,7 +183,7 @@ static void gemv_launch(const Gemv& g, hipStream_t st) {
 #undef Q3_GEMV_CASE
 }
 
-void gemv(const Gemv& g, Pro pro, Epi epi, hipStream_t st) {
+void gemv_generic(const Gemv& g, Pro pro, Epi epi, hipStream_t st) {
     if (pro == PRO_Q8 && epi == EPI_STORE) gemv_launch<PRO_Q8, EPI_STORE>(g, st);
     else if (pro == PRO_Q8 && epi == EPI_RESID) gemv_launch<PRO_Q8, EPI_RESID>(g, st);
     else if (pro == PRO_NORM && epi == EPI_STORE) gemv_launch<PRO_NORM, EPI_STORE>(g, st);
@@ -266,58 +197,6 @@ void gemv(const Gemv& g, Pro pro, Epi epi, hipStream_t st) {
 }
 
 // ------------------------------------------------------------ attention ----
-
-// RMSNorm (size HD, weight w) + half-split RoPE of one head held as float4 per
-// lane in lanes [0, HD/4) of a wave (reference forward.c:270-280, 104-118).
-// cs = (cos,sin) pairs of this position, [HD/2][2].
-template <int HD>
-__device__ __forceinline__ float4 headnorm_rope_wave(float4 v, const float* __restrict__ w,
-                                                     const float* __restrict__ cs, int lane) {
-    constexpr int L4 = HD / 4;
-    const bool act = lane < L4;
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-    if (act) {
-        c0 = c0 + v.x * v.x;
-        c1 = c1 + v.y * v.y;
-        c2 = c2 + v.z * v.z;
-        c3 = c3 + v.w * v.w;
-    }
-    const float ss = bfly64((c0 + c1) + (c2 + c3));
-    const float s = 1.0f / sqrtf(ss / (float)HD + 1e-6f);
-    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act) {
-        const float4 g = *reinterpret_cast<const float4*>(w + 4 * lane);
-        y.x = g.x * (s * v.x);
-        y.y = g.y * (s * v.y);
-        y.z = g.z * (s * v.z);
-        y.w = g.w * (s * v.w);
-    }
-    // element i < HD/2 pairs with i + HD/2: partner lane = lane ^ (L4/2)
-    float4 o;
-    o.x = shfl_xor_f(y.x, L4 / 2);
-    o.y = shfl_xor_f(y.y, L4 / 2);
-    o.z = shfl_xor_f(y.z, L4 / 2);
-    o.w = shfl_xor_f(y.w, L4 / 2);
-    float4 r = y;
-    if (act) {
-        const bool lo = lane < L4 / 2;
-        const int i0 = 4 * (lo ? lane : lane - L4 / 2);
-        const float4 ca = *reinterpret_cast<const float4*>(cs + 2 * i0);      // c0 s0 c1 s1
-        const float4 cb = *reinterpret_cast<const float4*>(cs + 2 * i0 + 4);  // c2 s2 c3 s3
-        if (lo) {   // own = real, other = imag: real*cos - imag*sin
-            r.x = y.x * ca.x - o.x * ca.y;
-            r.y = y.y * ca.z - o.y * ca.w;
-            r.z = y.z * cb.x - o.z * cb.y;
-            r.w = y.w * cb.z - o.w * cb.w;
-        } else {    // own = imag, other = real: real*sin + imag*cos
-            r.x = o.x * ca.y + y.x * ca.x;
-            r.y = o.y * ca.w + y.y * ca.z;
-            r.z = o.z * cb.y + y.z * cb.x;
-            r.w = o.w * cb.w + y.w * cb.z;
-        }
-    }
-    return r;
-}
 
 #define Q3_MAXG 8   // max query heads per kv head
 
@@ -457,10 +336,10 @@ __global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
                 }
             }
             float4 oth;
-            oth.x = shfl_xor_f(acc.x, 32);
-            oth.y = shfl_xor_f(acc.y, 32);
-            oth.z = shfl_xor_f(acc.z, 32);
-            oth.w = shfl_xor_f(acc.w, 32);
+            oth.x = lane_xor_f<32>(acc.x);
+            oth.y = lane_xor_f<32>(acc.y);
+            oth.z = lane_xor_f<32>(acc.z);
+            oth.w = lane_xor_f<32>(acc.w);
             if (half == 0 && l < L4) {
                 float4 sum;
                 sum.x = acc.x + oth.x;
@@ -598,8 +477,8 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* __restrict__ logit
         }
     }
     for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = shfl_xor_f(v, m);
-        const int oi = shfl_xor_i(idx, m);
+        const float ov = __shfl_xor(v, m, 64);
+        const int oi = __shfl_xor(idx, m, 64);
         if (ov > v || (ov == v && oi < idx)) {
             v = ov;
             idx = oi;
