@@ -270,20 +270,19 @@ static void attend_tree(const float* q, const float* k, const float* v, size_t s
             s[t - t0] = dot_tree(q, k + (size_t)t * stride, hd) / inv;
             if (t == t0 || s[t - t0] > mc) mc = s[t - t0];
         }
+        /* e_t is parked in lane 32*(t%2) + (t%64)/2 before the 64-lane butterfly */
         for (int i = 0; i < Q3_ATT_CHUNK; i++) e[i] = 0.0f;
-        for (int t = t0; t < t1; t++) e[t - t0] = q3_expf(s[t - t0] - mc);
         float a[Q3_ATT_STREAMS][128];
         memset(a, 0, sizeof(a));
         for (int t = t0; t < t1; t++) {
+            const int r = t - t0;
+            const float et = q3_expf(s[r] - mc);
+            e[32 * (r & 1) + (r >> 1)] = et;
             const float* vt = v + (size_t)t * stride;
-            float* as = a[t % Q3_ATT_STREAMS];
-            const float et = e[t - t0];
+            float* as = a[r & 1];
             for (int j = 0; j < hd; j++) as[j] = as[j] + et * vt[j];
         }
-        for (int j = 0; j < hd; j++) {
-            O[(size_t)c * 128 + j] = ((a[0][j] + a[1][j]) + (a[2][j] + a[3][j]))
-                                     + ((a[4][j] + a[5][j]) + (a[6][j] + a[7][j]));
-        }
+        for (int j = 0; j < hd; j++) O[(size_t)c * 128 + j] = a[0][j] + a[1][j];
         m[c] = mc;
         l[c] = butterfly(e, Q3_ATT_CHUNK);
     }

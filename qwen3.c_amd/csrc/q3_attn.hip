@@ -1,0 +1,320 @@
+// q3_attn.hip -- the attention stage of one decode step (reference src/forward.c:267-291):
+// per-head RMSNorm + RoPE of q and k, KV-cache append, grouped-query attention over the
+// cached positions, and q8_quantize of the head outputs for the Wo GEMV.
+//
+// One workgroup = one kv head x one 64-position chunk slot, 4 waves.  The K and V tiles
+// of a chunk are staged ONCE in LDS (64 KB at head_dim 128) and shared by the query heads
+// of the group (GQA: 4 query heads per kv head on Qwen3-4B/8B read each cached byte once).
+// Each wave then owns one query head end to end, so no cross-wave reduction is needed:
+//   scores   lanes = 2 positions x 32 float4 slices; per step a 4-term chain + 5-level
+//            butterfly inside each 32-lane half (q3_numerics.h DOT); the score of
+//            position t = 2*step + half is parked in lane 32*half + step
+//   softmax  wave max, q3_expf, 64-lane butterfly of the parked e_t
+//   PV       two streams (even / odd positions), each lane a float4 slice of the head
+// Every load that does not depend on data computed here is issued at kernel entry --
+// position, raw q/k/v, norm weights, the (cos,sin) row of this position and,
+// speculatively, the whole first K/V tile -- so the step costs one memory round trip.
+//
+// Chunk partials (m_c, l_c, O_c) are merged by k_attn_combine when pos >= 64; below
+// that the kernel normalises and quantises directly.
+#include <cstdio>
+#include <cstdlib>
+
+#include "q3_device.hpp"
+#include "q3_kernels.hpp"
+
+namespace q3k {
+
+#define Q3_MAXG 8   // max query heads per kv head
+
+#ifdef Q3_ATTN_STAMPS
+#define STAMP(i) do { if (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.stamps[2*(i)] = __builtin_amdgcn_s_memrealtime(); a.stamps[2*(i)+1] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
+    constexpr int L4 = HD / 4;               // lanes holding one head as float4
+    constexpr int CH = Q3_ATT_CHUNK;
+    constexpr int NLD = CH * L4 / 256;       // float4 loads per thread per tile
+    __shared__ __attribute__((aligned(16))) float Ks[CH * HD];
+    __shared__ __attribute__((aligned(16))) float Vs[CH * HD];
+
+    const int g = blockIdx.x;
+    const int kv_mul = a.n_heads / a.n_kv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int half = lane >> 5, l = lane & 31;
+    const int P = a.n_heads * HD, KVD = a.n_kv * HD;
+    const bool act = l < L4;
+    const size_t cbase = (size_t)g * a.seq_len * HD;
+
+    STAMP(0);
+    // ---- everything that can be requested before any arithmetic ------------------
+    const int pos = a.ctl->pos;
+    float4 kt[NLD], vt[NLD];
+    {
+        const int t0 = (int)blockIdx.y * CH;    // speculative: rows beyond pos are never used
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int idx = tid + k * 256;
+            const int t = idx / L4, l4 = idx - t * L4;
+            kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
+            vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
+        }
+    }
+    float4 kraw = make_float4(0.f, 0.f, 0.f, 0.f), vraw = kraw, qraw = kraw, qg = kraw, kg = kraw;
+    float4 ca = kraw, cb = kraw;
+    if (lane < L4) {
+        kraw = *reinterpret_cast<const float4*>(a.qkv + P + (size_t)g * HD + 4 * lane);
+        vraw = *reinterpret_cast<const float4*>(a.qkv + P + KVD + (size_t)g * HD + 4 * lane);
+        if (wave < kv_mul) qraw = *reinterpret_cast<const float4*>(a.qkv + (size_t)(g * kv_mul + wave) * HD + 4 * lane);
+        if (!a.prepared) {
+            qg = *reinterpret_cast<const float4*>(a.qnw + 4 * lane);
+            kg = *reinterpret_cast<const float4*>(a.knw + 4 * lane);
+        }
+    }
+    if (!a.prepared) rope_slices<HD>(a.cs, lane, ca, cb);
+
+    const int T = pos + 1;
+    const int nchunks = (T + CH - 1) / CH;
+    if ((int)blockIdx.y >= nchunks) return;
+    STAMP(1);
+    const bool owner = ((nchunks - 1) % (int)gridDim.y) == (int)blockIdx.y;
+
+    // k of this step: norm + rope, every wave redundantly (no barrier); wave 0 of the
+    // owning workgroup appends k and v to the cache
+    float4 kcur = kraw;
+    if (!a.prepared) kcur = headnorm_rope_vals<HD>(kraw, kg, ca, cb, lane);
+    if (owner && wave == 0 && lane < L4) {
+        *reinterpret_cast<float4*>(a.kc + cbase + (size_t)pos * HD + 4 * lane) = kcur;
+        *reinterpret_cast<float4*>(a.vc + cbase + (size_t)pos * HD + 4 * lane) = vraw;
+    }
+
+    STAMP(2);
+    const float root = sqrtf((float)HD);
+    bool first = true;
+    for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
+        const int t0 = c * CH;
+        const int Tc = (T - t0 < CH) ? T - t0 : CH;      // valid positions in this chunk
+        if (!first) {
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const int idx = tid + k * 256;
+                const int t = idx / L4, l4 = idx - t * L4;
+                if (t < Tc) {
+                    kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
+                    vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
+                }
+            }
+            __syncthreads();      // the previous chunk's tiles are no longer being read
+        }
+        first = false;
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int idx = tid + k * 256;
+            const int t = idx / L4, l4 = idx - t * L4;
+            if (t0 + t != pos) {      // the row of this very step comes from registers below
+                *reinterpret_cast<float4*>(Ks + t * HD + 4 * l4) = kt[k];
+                *reinterpret_cast<float4*>(Vs + t * HD + 4 * l4) = vt[k];
+            }
+        }
+        if (wave == 1 && lane < L4 && pos >= t0 && pos < t0 + CH) {
+            *reinterpret_cast<float4*>(Ks + (pos - t0) * HD + 4 * lane) = kcur;
+            *reinterpret_cast<float4*>(Vs + (pos - t0) * HD + 4 * lane) = vraw;
+        }
+        __syncthreads();
+        STAMP(3);
+
+        const int nsteps = (Tc + 1) >> 1;
+        for (int i = wave; i < kv_mul; i += 4) {
+            const int h = g * kv_mul + i;
+            // q of this head: norm + rope in lanes [0, L4), then mirrored into the upper half
+            float4 q4 = qraw;        // preloaded for the first head of this wave
+            if (i != wave && lane < L4) q4 = *reinterpret_cast<const float4*>(a.qkv + (size_t)h * HD + 4 * lane);
+            if (!a.prepared) q4 = headnorm_rope_vals<HD>(q4, qg, ca, cb, lane);
+            if (a.qdbg && blockIdx.y == 0 && lane < L4) *reinterpret_cast<float4*>(a.qdbg + (size_t)h * HD + 4 * lane) = q4;
+            {
+                const float ox = lane_xor_f<32>(q4.x), oy = lane_xor_f<32>(q4.y);
+                const float oz = lane_xor_f<32>(q4.z), ow = lane_xor_f<32>(q4.w);
+                if (half) q4 = make_float4(ox, oy, oz, ow);
+            }
+            // scores: step s handles position t = 2*s + half; the 4-term chains of all 32
+            // steps are formed first, then ONE transposing butterfly leaves the finished
+            // dot of step l in lane l of each half (= lane 32*half + l of the wave)
+            float cpart[32];
+#pragma unroll
+            for (int blk = 0; blk < 4; blk++) {
+                if (8 * blk < nsteps) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int step = 8 * blk + k;
+                        const int t = 2 * step + half;
+                        float cdot = 0.0f;
+                        if (act) {      // rows >= Tc hold stale bytes; their sums are masked below
+                            const float4 k4 = *reinterpret_cast<const float4*>(Ks + t * HD + 4 * l);
+                            cdot = q4.x * k4.x;
+                            cdot = cdot + q4.y * k4.y;
+                            cdot = cdot + q4.z * k4.z;
+                            cdot = cdot + q4.w * k4.w;
+                        }
+                        cpart[step] = cdot;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) cpart[8 * blk + k] = 0.0f;
+                }
+            }
+            STAMP(4);
+            const float dot = transpose_sum32(cpart, l);
+            const bool valid = (2 * l + half) < Tc;
+            const float mys = valid ? dot / root : -3.0e38f;
+            const float m = wave_max(mys);
+            const float e = valid ? q3_expf(mys - m) : 0.0f;
+            const float lsum = bfly64(e);
+            STAMP(5);
+            // weighted sum of V: stream `half` takes positions half, half+2, ...
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int blk = 0; blk < 4; blk++) {
+                if (8 * blk < nsteps) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int step = 8 * blk + k;
+                        const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), step));
+                        const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), 32 + step));
+                        const float et = half ? e1 : e0;
+                        const int t = 2 * step + half;
+                        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (act) v4 = *reinterpret_cast<const float4*>(Vs + t * HD + 4 * l);
+                        const bool on = t < Tc;
+                        acc.x = on ? acc.x + et * v4.x : acc.x;
+                        acc.y = on ? acc.y + et * v4.y : acc.y;
+                        acc.z = on ? acc.z + et * v4.z : acc.z;
+                        acc.w = on ? acc.w + et * v4.w : acc.w;
+                    }
+                }
+            }
+            STAMP(6);
+            float4 o;
+            o.x = acc.x + lane_xor_f<32>(acc.x);
+            o.y = acc.y + lane_xor_f<32>(acc.y);
+            o.z = acc.z + lane_xor_f<32>(acc.z);
+            o.w = acc.w + lane_xor_f<32>(acc.w);
+            if (multi) {
+                if (lane < L4) {
+                    float* pp = a.part + ((size_t)h * a.max_chunks + c) * (HD + 2);
+                    *reinterpret_cast<float2*>(pp + 4 * lane) = make_float2(o.x, o.y);
+                    *reinterpret_cast<float2*>(pp + 4 * lane + 2) = make_float2(o.z, o.w);
+                    if (lane == 0) {
+                        pp[HD] = m;
+                        pp[HD + 1] = lsum;
+                    }
+                }
+            } else {
+                // q8_quantize of the head output (forward.c:291): 64-wide groups of 16 lanes
+                float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane < L4) {
+                    y.x = o.x / lsum;
+                    y.y = o.y / lsum;
+                    y.z = o.z / lsum;
+                    y.w = o.w / lsum;
+                }
+                float scale;
+                const int packed = quantize_group16(y, scale);
+                if (lane < L4) {
+                    reinterpret_cast<int*>(a.oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
+                    if ((lane & 15) == 0) a.os[((size_t)h * HD + 4 * lane) >> 6] = scale;
+                    if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
+                }
+            }
+        }
+    }
+    STAMP(7);
+}
+
+// merge of the chunk partials (q3_numerics.h "attention", last three lines) + quantise
+template <int HD>
+__global__ __launch_bounds__(64) void k_attn_combine(Attn a) {
+    constexpr int L4 = HD / 4;
+    const int h = blockIdx.x, lane = threadIdx.x;
+    const int T = a.ctl->pos + 1;
+    const int nchunks = (T + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
+    const float* base = a.part + (size_t)h * a.max_chunks * (HD + 2);
+    float M = base[HD];
+    for (int c = 1; c < nchunks; c++) M = fmaxf(M, base[(size_t)c * (HD + 2) + HD]);
+    float L = 0.0f;
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < nchunks; c++) {
+        const float* pp = base + (size_t)c * (HD + 2);
+        const float w = q3_expf(pp[HD] - M);
+        L = L + w * pp[HD + 1];
+        if (lane < L4) {
+            const float2 o01 = *reinterpret_cast<const float2*>(pp + 4 * lane);
+            const float2 o23 = *reinterpret_cast<const float2*>(pp + 4 * lane + 2);
+            A.x = A.x + w * o01.x;
+            A.y = A.y + w * o01.y;
+            A.z = A.z + w * o23.x;
+            A.w = A.w + w * o23.y;
+        }
+    }
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < L4) {
+        y.x = A.x / L;
+        y.y = A.y / L;
+        y.z = A.z / L;
+        y.w = A.w / L;
+    }
+    float scale;
+    const int packed = quantize_group16(y, scale);
+    if (lane < L4) {
+        reinterpret_cast<int*>(a.oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
+        if ((lane & 15) == 0) a.os[((size_t)h * HD + 4 * lane) >> 6] = scale;
+        if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
+    }
+}
+
+void attn(const Attn& a, int chunk_slots, bool multi, hipStream_t st) {
+    if (a.n_heads / a.n_kv > Q3_MAXG) {
+        fprintf(stderr, "[q3hip] attention: more than %d query heads per kv head\n", Q3_MAXG);
+        exit(EXIT_FAILURE);
+    }
+    dim3 grid(a.n_kv, chunk_slots);
+    if (a.hd == 128) hipLaunchKernelGGL(k_attn<128>, grid, dim3(256), 0, st, a, multi ? 1 : 0);
+    else if (a.hd == 64) hipLaunchKernelGGL(k_attn<64>, grid, dim3(256), 0, st, a, multi ? 1 : 0);
+    else {
+        fprintf(stderr, "[q3hip] attention: head_dim %d not supported (64 or 128)\n", a.hd);
+        exit(EXIT_FAILURE);
+    }
+}
+
+void attn_combine(const Attn& a, hipStream_t st) {
+    if (a.hd == 128) hipLaunchKernelGGL(k_attn_combine<128>, dim3(a.n_heads), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(k_attn_combine<64>, dim3(a.n_heads), dim3(64), 0, st, a);
+}
+
+// start of a step on one device: embedding row (when this stage owns it) and the
+// (cos,sin) row of `pos` copied to a fixed address so that no later load depends on pos
+__global__ __launch_bounds__(256) void k_begin(const Ctl* ctl, const int8_t* __restrict__ eq,
+                                               const float* __restrict__ es, int dim, float* __restrict__ x,
+                                               const float* __restrict__ rope, int hd, float* __restrict__ cs) {
+    const int pos = ctl->pos;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < hd; i += 256) cs[i] = rope[(size_t)pos * hd + i];
+    }
+    if (eq) {
+        // x = q*s of one embedding row (reference model.c:201-206 dequantises the whole table
+        // on the host and forward.c:237 copies a row; the product q*s is the same single rounding)
+        const size_t base = (size_t)ctl->token * dim;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < dim; i += gridDim.x * 256) {
+            x[i] = (float)eq[base + i] * es[(base + i) >> 6];
+        }
+    }
+}
+void begin_step(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, const float* rope,
+                int hd, float* cs, hipStream_t st) {
+    const int blocks = eq ? (dim + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(256), 0, st, ctl, eq, es, dim, x, rope, hd, cs);
+}
+
+}  // namespace q3k

@@ -120,9 +120,24 @@ __device__ __forceinline__ int quad_sum(int d) {
 // RMSNorm (size HD, weight w) + half-split RoPE of one head held as float4 per lane in
 // lanes [0, HD/4) of a wave (reference forward.c:270-280, 104-118).
 // cs = (cos,sin) pairs of this position, [HD/2][2].
+// (cos,sin) slices a lane needs for RoPE of its float4: elements i0..i0+3 of the pair index
 template <int HD>
-__device__ __forceinline__ float4 headnorm_rope_wave(float4 v, const float* __restrict__ w,
-                                                     const float* __restrict__ cs, int lane) {
+__device__ __forceinline__ void rope_slices(const float* __restrict__ cs, int lane, float4& ca, float4& cb) {
+    constexpr int L4 = HD / 4;
+    ca = make_float4(0.f, 0.f, 0.f, 0.f);
+    cb = ca;
+    if (lane < L4) {
+        const int i0 = 4 * (lane < L4 / 2 ? lane : lane - L4 / 2);
+        ca = *reinterpret_cast<const float4*>(cs + 2 * i0);      // c0 s0 c1 s1
+        cb = *reinterpret_cast<const float4*>(cs + 2 * i0 + 4);  // c2 s2 c3 s3
+    }
+}
+
+// RMSNorm (size HD, weight slice g) + half-split RoPE of one head held as float4 per lane
+// in lanes [0, HD/4) of a wave (reference forward.c:270-280, 104-118); all operands in
+// registers, so callers can issue the loads long before.
+template <int HD>
+__device__ __forceinline__ float4 headnorm_rope_vals(float4 v, float4 g, float4 ca, float4 cb, int lane) {
     constexpr int L4 = HD / 4;
     const bool act = lane < L4;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
@@ -136,7 +151,6 @@ __device__ __forceinline__ float4 headnorm_rope_wave(float4 v, const float* __re
     const float s = 1.0f / sqrtf(ss / (float)HD + 1e-6f);
     float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
     if (act) {
-        const float4 g = *reinterpret_cast<const float4*>(w + 4 * lane);
         y.x = g.x * (s * v.x);
         y.y = g.y * (s * v.y);
         y.z = g.z * (s * v.z);
@@ -150,16 +164,12 @@ __device__ __forceinline__ float4 headnorm_rope_wave(float4 v, const float* __re
     o.w = lane_xor_f<L4 / 2>(y.w);
     float4 r = y;
     if (act) {
-        const bool lo = lane < L4 / 2;
-        const int i0 = 4 * (lo ? lane : lane - L4 / 2);
-        const float4 ca = *reinterpret_cast<const float4*>(cs + 2 * i0);      // c0 s0 c1 s1
-        const float4 cb = *reinterpret_cast<const float4*>(cs + 2 * i0 + 4);  // c2 s2 c3 s3
-        if (lo) {   // own = real, other = imag: real*cos - imag*sin
+        if (lane < L4 / 2) {   // own = real, other = imag: real*cos - imag*sin
             r.x = y.x * ca.x - o.x * ca.y;
             r.y = y.y * ca.z - o.y * ca.w;
             r.z = y.z * cb.x - o.z * cb.y;
             r.w = y.w * cb.z - o.w * cb.w;
-        } else {    // own = imag, other = real: real*sin + imag*cos
+        } else {               // own = imag, other = real: real*sin + imag*cos
             r.x = o.x * ca.y + y.x * ca.x;
             r.y = o.y * ca.w + y.y * ca.z;
             r.z = o.z * cb.y + y.z * cb.x;
@@ -167,6 +177,38 @@ __device__ __forceinline__ float4 headnorm_rope_wave(float4 v, const float* __re
         }
     }
     return r;
+}
+
+template <int HD>
+__device__ __forceinline__ float4 headnorm_rope_wave(float4 v, const float* __restrict__ w,
+                                                     const float* __restrict__ cs, int lane) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), ca, cb;
+    if (lane < HD / 4) g = *reinterpret_cast<const float4*>(w + 4 * lane);
+    rope_slices<HD>(cs, lane, ca, cb);
+    return headnorm_rope_vals<HD>(v, g, ca, cb, lane);
+}
+
+// Transposing butterfly: every lane l of a 32-lane half holds 32 partial values
+// c[s] (s = 0..31); returns, in lane l, the sum over the half's lanes of c[l],
+// added in exactly the tree of bfly32 (pairs xor 16, 8, 4, 2, 1).  31 exchanges
+// instead of 32 x 5, and each level's exchanges are independent of one another.
+__device__ __forceinline__ float transpose_sum32(float (&c)[32], int l) {
+#define Q3_TS_LEVEL(M, CNT)                                              \
+    {                                                                    \
+        const bool up = (l & M) != 0;                                    \
+        _Pragma("unroll") for (int k = 0; k < CNT; k++) {                \
+            const float keep = up ? c[k + CNT] : c[k];                   \
+            const float send = up ? c[k] : c[k + CNT];                   \
+            c[k] = keep + lane_xor_f<M>(send);                           \
+        }                                                                \
+    }
+    Q3_TS_LEVEL(16, 16)
+    Q3_TS_LEVEL(8, 8)
+    Q3_TS_LEVEL(4, 4)
+    Q3_TS_LEVEL(2, 2)
+    Q3_TS_LEVEL(1, 1)
+#undef Q3_TS_LEVEL
+    return c[0];
 }
 
 }  // namespace q3k

@@ -196,257 +196,6 @@ void gemv_generic(const Gemv& g, Pro pro, Epi epi, hipStream_t st) {
     }
 }
 
-// ------------------------------------------------------------ attention ----
-
-#define Q3_MAXG 8   // max query heads per kv head
-
-template <int HD>
-__global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
-    constexpr int L4 = HD / 4;
-    constexpr int CH = Q3_ATT_CHUNK;
-    __shared__ __attribute__((aligned(16))) float Ks[CH * HD];
-    __shared__ __attribute__((aligned(16))) float Vs[CH * HD];
-    __shared__ __attribute__((aligned(16))) float qs[Q3_MAXG * HD];
-    __shared__ __attribute__((aligned(16))) float kcur[HD];
-    __shared__ __attribute__((aligned(16))) float vcur[HD];
-    __shared__ float sc[Q3_MAXG * CH];
-    __shared__ float es[Q3_MAXG * CH];
-    __shared__ float mc[Q3_MAXG];
-    __shared__ float lc[Q3_MAXG];
-    float* red = Ks;   // [4][kv_mul][HD], reused after the score phase
-    float* ofin = Vs;  // [kv_mul][HD], reused after the PV phase
-
-    const int g = blockIdx.x;
-    const int kv_mul = a.n_heads / a.n_kv;
-    const int pos = a.ctl->pos;
-    const int T = pos + 1;
-    const int nchunks = (T + CH - 1) / CH;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int P = a.n_heads * HD, KVD = a.n_kv * HD;
-    const float* cs = a.rope + (size_t)pos * HD;   // [HD/2][2]
-    const bool owner = ((nchunks - 1) % (int)gridDim.y) == (int)blockIdx.y;
-    if ((int)blockIdx.y >= nchunks) return;
-
-    // q heads of this kv group: norm + rope -> qs
-    for (int i = wave; i < kv_mul; i += 4) {
-        const int h = g * kv_mul + i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < L4) v = *reinterpret_cast<const float4*>(a.qkv + (size_t)h * HD + 4 * lane);
-        const float4 r = a.prepared ? v : headnorm_rope_wave<HD>(v, a.qnw, cs, lane);
-        if (lane < L4) {
-            *reinterpret_cast<float4*>(qs + i * HD + 4 * lane) = r;
-            if (a.qdbg && blockIdx.y == 0) *reinterpret_cast<float4*>(a.qdbg + (size_t)h * HD + 4 * lane) = r;
-        }
-    }
-    // the workgroup that owns the last chunk appends k (norm + rope) and v at `pos`
-    if (owner) {
-        if (wave == 0) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lane < L4) v = *reinterpret_cast<const float4*>(a.qkv + P + (size_t)g * HD + 4 * lane);
-            const float4 r = a.prepared ? v : headnorm_rope_wave<HD>(v, a.knw, cs, lane);
-            if (lane < L4) {
-                *reinterpret_cast<float4*>(kcur + 4 * lane) = r;
-                *reinterpret_cast<float4*>(a.kc + ((size_t)g * a.seq_len + pos) * HD + 4 * lane) = r;
-            }
-        } else if (wave == 1) {
-            if (lane < L4) {
-                const float4 v = *reinterpret_cast<const float4*>(a.qkv + P + KVD + (size_t)g * HD + 4 * lane);
-                *reinterpret_cast<float4*>(vcur + 4 * lane) = v;
-                *reinterpret_cast<float4*>(a.vc + ((size_t)g * a.seq_len + pos) * HD + 4 * lane) = v;
-            }
-        }
-    }
-    __syncthreads();
-
-    const float root = sqrtf((float)HD);
-    for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
-        const int t0 = c * CH;
-        // stage the K and V tiles of this chunk in LDS
-        for (int idx = tid; idx < CH * L4; idx += 256) {
-            const int t = idx / L4, l4 = idx - t * L4;
-            const int tt = t0 + t;
-            if (tt < T) {
-                float4 kk, vv;
-                if (tt == pos) {
-                    kk = *reinterpret_cast<const float4*>(kcur + 4 * l4);
-                    vv = *reinterpret_cast<const float4*>(vcur + 4 * l4);
-                } else {
-                    kk = *reinterpret_cast<const float4*>(a.kc + ((size_t)g * a.seq_len + tt) * HD + 4 * l4);
-                    vv = *reinterpret_cast<const float4*>(a.vc + ((size_t)g * a.seq_len + tt) * HD + 4 * l4);
-                }
-                *reinterpret_cast<float4*>(Ks + t * HD + 4 * l4) = kk;
-                *reinterpret_cast<float4*>(Vs + t * HD + 4 * l4) = vv;
-            }
-        }
-        __syncthreads();
-
-        // scores: wave w owns positions [16w, 16w+16), two per step (one per 32-lane half)
-        const int half = lane >> 5, l = lane & 31;
-        for (int i = 0; i < kv_mul; i++) {
-            float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (l < L4) q4 = *reinterpret_cast<const float4*>(qs + i * HD + 4 * l);
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int t = wave * 16 + it * 2 + half;
-                float cdot = 0.0f;
-                if (l < L4 && t0 + t < T) {
-                    const float4 k4 = *reinterpret_cast<const float4*>(Ks + t * HD + 4 * l);
-                    cdot = q4.x * k4.x;
-                    cdot = cdot + q4.y * k4.y;
-                    cdot = cdot + q4.z * k4.z;
-                    cdot = cdot + q4.w * k4.w;
-                }
-                cdot = bfly32(cdot);
-                if (l == 0) sc[i * CH + t] = cdot / root;
-            }
-        }
-        __syncthreads();
-
-        // chunk softmax statistics: one wave per head, lane = position
-        for (int i = wave; i < kv_mul; i += 4) {
-            const bool valid = t0 + lane < T;
-            const float s = valid ? sc[i * CH + lane] : -3.0e38f;
-            const float m = wave_max(s);
-            const float e = valid ? q3_expf(s - m) : 0.0f;
-            const float lsum = bfly64(e);
-            es[i * CH + lane] = e;
-            if (lane == 0) {
-                mc[i] = m;
-                lc[i] = lsum;
-            }
-        }
-        __syncthreads();
-
-        // weighted sum of V: stream s = t % 8 -> (wave = s/2, half = s%2)
-        const int strm = 2 * wave + half;
-        for (int i = 0; i < kv_mul; i++) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (l < L4) {
-#pragma unroll
-                for (int mm = 0; mm < 8; mm++) {
-                    const int t = 8 * mm + strm;
-                    if (t0 + t < T) {
-                        const float e = es[i * CH + t];
-                        const float4 v4 = *reinterpret_cast<const float4*>(Vs + t * HD + 4 * l);
-                        acc.x = acc.x + e * v4.x;
-                        acc.y = acc.y + e * v4.y;
-                        acc.z = acc.z + e * v4.z;
-                        acc.w = acc.w + e * v4.w;
-                    }
-                }
-            }
-            float4 oth;
-            oth.x = lane_xor_f<32>(acc.x);
-            oth.y = lane_xor_f<32>(acc.y);
-            oth.z = lane_xor_f<32>(acc.z);
-            oth.w = lane_xor_f<32>(acc.w);
-            if (half == 0 && l < L4) {
-                float4 sum;
-                sum.x = acc.x + oth.x;
-                sum.y = acc.y + oth.y;
-                sum.z = acc.z + oth.z;
-                sum.w = acc.w + oth.w;
-                *reinterpret_cast<float4*>(red + (wave * kv_mul + i) * HD + 4 * l) = sum;
-            }
-        }
-        __syncthreads();
-
-        for (int idx = tid; idx < kv_mul * HD; idx += 256) {
-            const int i = idx / HD, j = idx - i * HD;
-            const float o = (red[(0 * kv_mul + i) * HD + j] + red[(1 * kv_mul + i) * HD + j])
-                            + (red[(2 * kv_mul + i) * HD + j] + red[(3 * kv_mul + i) * HD + j]);
-            const int h = g * kv_mul + i;
-            if (multi) {
-                float* pp = a.part + ((size_t)h * a.max_chunks + c) * (HD + 2);
-                pp[j] = o;
-                if (j == 0) {
-                    pp[HD] = mc[i];
-                    pp[HD + 1] = lc[i];
-                }
-            } else {
-                ofin[i * HD + j] = o / lc[i];
-            }
-        }
-        __syncthreads();
-        if (!multi) {
-            // q8_quantize of the head outputs (forward.c:291): 2 groups per 128-wide head
-            for (int i = wave; i < kv_mul; i += 4) {
-                const int h = g * kv_mul + i;
-                float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (lane < L4) y = *reinterpret_cast<const float4*>(ofin + i * HD + 4 * lane);
-                float scale;
-                const int packed = quantize_group16(y, scale);
-                if (lane < L4) {
-                    reinterpret_cast<int*>(a.oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
-                    if ((lane & 15) == 0) a.os[((size_t)h * HD + 4 * lane) >> 6] = scale;
-                    if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// merge of the chunk partials (q3_numerics.h "attention", last three lines) + quantise
-template <int HD>
-__global__ __launch_bounds__(64) void k_attn_combine(Attn a) {
-    constexpr int L4 = HD / 4;
-    const int h = blockIdx.x, lane = threadIdx.x;
-    const int T = a.ctl->pos + 1;
-    const int nchunks = (T + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
-    const float* base = a.part + (size_t)h * a.max_chunks * (HD + 2);
-    float M = base[HD];
-    for (int c = 1; c < nchunks; c++) M = fmaxf(M, base[(size_t)c * (HD + 2) + HD]);
-    float L = 0.0f;
-    float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < nchunks; c++) {
-        const float* pp = base + (size_t)c * (HD + 2);
-        const float w = q3_expf(pp[HD] - M);
-        L = L + w * pp[HD + 1];
-        if (lane < L4) {
-            const float2 o01 = *reinterpret_cast<const float2*>(pp + 4 * lane);
-            const float2 o23 = *reinterpret_cast<const float2*>(pp + 4 * lane + 2);
-            A.x = A.x + w * o01.x;
-            A.y = A.y + w * o01.y;
-            A.z = A.z + w * o23.x;
-            A.w = A.w + w * o23.y;
-        }
-    }
-    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < L4) {
-        y.x = A.x / L;
-        y.y = A.y / L;
-        y.z = A.z / L;
-        y.w = A.w / L;
-    }
-    float scale;
-    const int packed = quantize_group16(y, scale);
-    if (lane < L4) {
-        reinterpret_cast<int*>(a.oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
-        if ((lane & 15) == 0) a.os[((size_t)h * HD + 4 * lane) >> 6] = scale;
-        if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
-    }
-}
-
-void attn(const Attn& a, int chunk_slots, bool multi, hipStream_t st) {
-    if (a.n_heads / a.n_kv > Q3_MAXG) {
-        fprintf(stderr, "[q3hip] attention: more than %d query heads per kv head\n", Q3_MAXG);
-        exit(EXIT_FAILURE);
-    }
-    dim3 grid(a.n_kv, chunk_slots);
-    if (a.hd == 128) hipLaunchKernelGGL(k_attn<128>, grid, dim3(256), 0, st, a, multi ? 1 : 0);
-    else if (a.hd == 64) hipLaunchKernelGGL(k_attn<64>, grid, dim3(256), 0, st, a, multi ? 1 : 0);
-    else {
-        fprintf(stderr, "[q3hip] attention: head_dim %d not supported (64 or 128)\n", a.hd);
-        exit(EXIT_FAILURE);
-    }
-}
-
-void attn_combine(const Attn& a, hipStream_t st) {
-    if (a.hd == 128) hipLaunchKernelGGL(k_attn_combine<128>, dim3(a.n_heads), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(k_attn_combine<64>, dim3(a.n_heads), dim3(64), 0, st, a);
-}
-
 // ------------------------------------------------------------- small ops ---
 
 // x = q*s of one embedding row (reference model.c:201-206 dequantises the whole table

@@ -37,15 +37,16 @@ struct Attn {
     const float* qkv;    // raw projections of this step: q[P] | k[KVD] | v[KVD]
     const float* qnw;    // per-layer q head-norm weight [hd]
     const float* knw;    // per-layer k head-norm weight [hd]
-    const float* rope;   // [seq_len][hd/2][2] (cos, sin)
-    float* kc;           // this layer's K cache [n_kv][seq_len][hd]
-    float* vc;           // this layer's V cache [n_kv][seq_len][hd]
+    const float* cs;     // (cos, sin) row of this step's position, [hd/2][2] (written by begin_step)
+    float* kc;           // this layer's K cache [n_kv][seq_len][hd], seq_len a multiple of 64
+    float* vc;           // this layer's V cache, same layout
     float* part;         // chunk partials [n_heads][max_chunks][hd+2]
     int8_t* oq;          // attention output codes [P]
     float* os;           // attention output scales [P/64]
     float* of;           // optional fp32 copy of the head outputs [P] (may be null)
     float* qdbg;         // optional: normed+rotated q [P] (may be null)
     int n_heads, n_kv, hd, seq_len, max_chunks;
+    unsigned long long* stamps;  // diagnostic builds only: s_memrealtime/s_memtime marks of workgroup (0,0)
     int prepared;        // op-level test hook only: q and the k/v of `pos` are already normed + rotated
 };
 // `chunk_slots` workgroups per kv head walk the 64-position chunks of [0,pos];
@@ -55,6 +56,10 @@ void attn(const Attn& a, int chunk_slots, bool multi, hipStream_t st);
 void attn_combine(const Attn& a, hipStream_t st);
 
 void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, hipStream_t st);
+// first kernel of a step: x = embedding row of ctl->token (eq may be null on later pipeline
+// stages) and cs = rope[ctl->pos]
+void begin_step(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, const float* rope,
+                int hd, float* cs, hipStream_t st);
 void argmax(const float* logits, int n, int* out, Ctl* ctl_next, hipStream_t st);
 
 // stand-alone ops behind the reference's exported symbols / the op-level tests

@@ -30,9 +30,10 @@
  *                         ((q0k0+q1k1)+q2k2)+q3k3 of elements 4l..4l+3,
  *                         butterfly over 32 lanes xor 16,8,4,2,1
  *                   m_c = max s_t ; e_t = q3_expf(s_t - m_c)
- *                   l_c = butterfly-64 sum of e_t (lane = t%64)
- *                   O_c[j] = stream tree: a_s[j] += e_t*v_t[j] for t%8==s
- *                            ascending, ((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7))
+ *                   l_c = butterfly-64 sum of e_t, e_t sitting in lane
+ *                         32*(t%2) + (t%64)/2   (how the kernel parks the scores)
+ *                   O_c[j] = two streams: a_h[j] += e_t*v_t[j] for t%2==h,
+ *                            ascending t; O_c = a_0 + a_1
  *                 M = max m_c ; w_c = q3_expf(m_c - M)
  *                 L = sum_c w_c*l_c ; A[j] = sum_c w_c*O_c[j] (ascending c)
  *                 out[j] = A[j]/L                                    [src/forward.c:141-195]
@@ -55,7 +56,7 @@
 #endif
 
 #define Q3_ATT_CHUNK 64      /* cache positions per attention chunk          */
-#define Q3_ATT_STREAMS 8     /* interleaved accumulation streams per chunk   */
+#define Q3_ATT_STREAMS 2     /* interleaved accumulation streams per chunk   */
 #define Q3_MM_COLS 16        /* column partials of the matmul group sum      */
 
 Q3_HD float q3_bits_to_float(uint32_t u) {

@@ -76,6 +76,7 @@ struct Dev {
     int device = 0;
     hipStream_t st = nullptr;
     int dim = 0, hid = 0, L = 0, H = 0, KV = 0, hd = 0, P = 0, KVD = 0, V = 0, seq = 0;
+    int seq_pad = 0;             // cache rows per kv head: seq rounded up to the 64-position chunk
     int l0 = 0, l1 = 0;          // layers [l0, l1) live on this device
     bool has_embed = true, has_cls = true;
     std::vector<LayerDev> layers; // indexed by global layer id; only [l0,l1) filled
@@ -83,10 +84,11 @@ struct Dev {
     int8_t *emb_q = nullptr, *cls_q = nullptr, *att_q = nullptr;
     float *emb_s = nullptr, *cls_s = nullptr, *out_nw = nullptr;
     float *x = nullptr, *qkv = nullptr, *h = nullptr, *logits = nullptr, *att_s = nullptr;
-    float *att_f = nullptr, *part = nullptr, *rope = nullptr, *tap_dev = nullptr;
+    float *att_f = nullptr, *part = nullptr, *rope = nullptr, *tap_dev = nullptr, *cs_cur = nullptr;
     q3k::Ctl* ctl = nullptr;
     q3k::Ctl* ctl_host = nullptr;
     int* amax = nullptr;
+    unsigned long long* stamps = nullptr;
     int* amax_host = nullptr;
     int max_chunks = 1, chunk_slots = 1;
     bool logits_pinned = false;
@@ -208,7 +210,7 @@ void upload_weights(Dev* d) {
         L.ffn_nw = upload<float>(d, w->ffn_rms_norm + (size_t)l * dim, dim);
         L.qnw = upload<float>(d, w->q_rms_norm + (size_t)l * hd, hd);
         L.knw = upload<float>(d, w->k_rms_norm + (size_t)l * hd, hd);
-        const size_t cache = (size_t)d->KV * d->seq * hd;
+        const size_t cache = (size_t)d->KV * d->seq_pad * hd;
         L.kc = dalloc<float>(d, cache);
         L.vc = dalloc<float>(d, cache);
         HIPCHK(hipMemsetAsync(L.kc, 0, cache * 4, d->st));
@@ -259,6 +261,7 @@ Dev* attach(Model* m) {
     d->dim = p->dim; d->hid = p->hidden_dim; d->L = p->n_layers; d->H = p->n_heads;
     d->KV = p->n_kv_heads; d->hd = p->head_dim; d->V = p->vocab_size; d->seq = p->seq_len;
     d->P = d->H * d->hd; d->KVD = d->KV * d->hd;
+    d->seq_pad = (d->seq + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK * Q3_ATT_CHUNK;
     d->l0 = 0; d->l1 = d->L;
     if (g_pipe.on) {
         int first, count;
@@ -279,12 +282,14 @@ Dev* attach(Model* m) {
     d->att_q = dalloc<int8_t>(d, d->P);
     d->att_s = dalloc<float>(d, d->P / 64);
     d->att_f = dalloc<float>(d, d->P);
+    d->cs_cur = dalloc<float>(d, d->hd);
     d->max_chunks = (d->seq + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
     d->chunk_slots = d->max_chunks < 64 ? d->max_chunks : 64;
     d->part = dalloc<float>(d, (size_t)d->H * d->max_chunks * (d->hd + 2));
     d->tap_dev = dalloc<float>(d, (size_t)d->L * d->dim);
     d->ctl = dalloc<q3k::Ctl>(d, 1);
     d->amax = dalloc<int>(d, 1);
+    if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 64); HIPCHK(hipMemset(d->stamps, 0, 64 * 8)); }
     HIPCHK(hipHostMalloc((void**)&d->ctl_host, sizeof(q3k::Ctl), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&d->amax_host, sizeof(int), hipHostMallocDefault));
     if (m->state.logits) {
@@ -367,10 +372,10 @@ void prof_collect(Dev* d) {
 q3k::Attn attn_args(Dev* d, int l) {
     const LayerDev& L = d->layers[l];
     q3k::Attn a;
-    a.ctl = d->ctl; a.qkv = d->qkv; a.qnw = L.qnw; a.knw = L.knw; a.rope = d->rope;
+    a.ctl = d->ctl; a.qkv = d->qkv; a.qnw = L.qnw; a.knw = L.knw; a.cs = d->cs_cur;
     a.kc = L.kc; a.vc = L.vc; a.part = d->part; a.oq = d->att_q; a.os = d->att_s;
-    a.of = nullptr; a.qdbg = nullptr; a.prepared = 0;
-    a.n_heads = d->H; a.n_kv = d->KV; a.hd = d->hd; a.seq_len = d->seq; a.max_chunks = d->max_chunks;
+    a.of = nullptr; a.qdbg = nullptr; a.prepared = 0; a.stamps = d->stamps;
+    a.n_heads = d->H; a.n_kv = d->KV; a.hd = d->hd; a.seq_len = d->seq_pad; a.max_chunks = d->max_chunks;
     return a;
 }
 
@@ -425,9 +430,10 @@ void enqueue_head(Dev* d) {
 
 // everything of one step that runs on this device, between the ctl upload and the logits
 void enqueue_step(Dev* d, bool multi) {
-    if (d->has_embed) {
-        Timed t(d, "embed", 0.0);
-        q3k::embed(d->ctl, d->emb_q, d->emb_s, d->dim, d->x, d->st);
+    {
+        Timed t(d, "begin", 0.0);
+        q3k::begin_step(d->ctl, d->has_embed ? d->emb_q : nullptr, d->emb_s, d->dim, d->x, d->rope, d->hd,
+                        d->cs_cur, d->st);
     }
     for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, multi);
     if (d->has_cls) enqueue_head(d);
@@ -538,6 +544,15 @@ extern "C" {
 
 const char* q3_version(void) { return "q3hip 0.1 (gfx950)"; }
 
+// diagnostic: copy the attention kernel's time stamps (Q3_STAMPS=1 + -DQ3_ATTN_STAMPS build)
+int q3_debug_stamps(Model* m, unsigned long long* out, int n) {
+    Dev* d = lookup(m);
+    if (!d || !d->stamps) return 0;
+    HIPCHK(hipStreamSynchronize(d->st));
+    HIPCHK(hipMemcpy(out, d->stamps, (size_t)(n < 64 ? n : 64) * 8, hipMemcpyDeviceToHost));
+    return n < 64 ? n : 64;
+}
+
 int q3_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -626,7 +641,7 @@ void q3_kv_fill_random(Model* m, int T, uint64_t seed) {
     if (T > d->seq) T = d->seq;
     for (int l = d->l0; l < d->l1; l++) {
         for (int g = 0; g < d->KV; g++) {
-            const size_t off = (size_t)g * d->seq * d->hd;
+            const size_t off = (size_t)g * d->seq_pad * d->hd;
             q3k::fill_random(d->layers[l].kc + off, (size_t)T * d->hd, seed + 2 * (l * 64 + g), d->st);
             q3k::fill_random(d->layers[l].vc + off, (size_t)T * d->hd, seed + 2 * (l * 64 + g) + 1, d->st);
         }
@@ -651,6 +666,7 @@ void q3_layer_step(Model* m, int layer, int pos, const float* x_in, float* x_out
     d->ctl_host->token = 0;
     d->ctl_host->pos = pos;
     HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
+    q3k::begin_step(d->ctl, nullptr, nullptr, d->dim, d->x, d->rope, d->hd, d->cs_cur, d->st);
     HIPCHK(hipMemcpyAsync(d->x, x_in, (size_t)d->dim * 4, hipMemcpyHostToDevice, d->st));
     enqueue_layer(d, layer, pos >= Q3_ATT_CHUNK);
     HIPCHK(hipStreamSynchronize(d->st));
@@ -733,6 +749,7 @@ void attention(Model* m, int layer, int pos) {
     d->ctl_host->token = 0;
     d->ctl_host->pos = pos;
     HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
+    q3k::begin_step(d->ctl, nullptr, nullptr, d->dim, d->x, d->rope, d->hd, d->cs_cur, d->st);
     q3k::Attn a = attn_args(d, layer);
     a.of = d->att_f;
     const bool multi = pos >= Q3_ATT_CHUNK;
@@ -805,7 +822,7 @@ void q3_op_attention(const float* q, const float* kcache, const float* vcache, i
     hipStream_t st = ops_stream();
     if (T < 1) Q3_DIE("attention: T must be >= 1");
     const int hd = head_dim, P = n_heads * hd, KVD = n_kv_heads * hd;
-    const int seq = T;
+    const int seq = (T + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK * Q3_ATT_CHUNK;
     // cache in device layout [n_kv][seq][hd]
     std::vector<float> kc((size_t)KVD * seq), vc((size_t)KVD * seq);
     for (int t = 0; t < T; t++) {
@@ -826,7 +843,7 @@ void q3_op_attention(const float* q, const float* kcache, const float* vcache, i
     DBuf dctl(&ctl, sizeof(ctl));
     q3k::Attn a;
     memset(&a, 0, sizeof(a));
-    a.ctl = dctl.as<q3k::Ctl>(); a.qkv = dqkv.as<float>(); a.qnw = nullptr; a.knw = nullptr; a.rope = nullptr;
+    a.ctl = dctl.as<q3k::Ctl>(); a.qkv = dqkv.as<float>(); a.qnw = nullptr; a.knw = nullptr; a.cs = nullptr;
     a.kc = dkc.as<float>(); a.vc = dvc.as<float>(); a.part = dpart.as<float>();
     a.oq = doq.as<int8_t>(); a.os = dos.as<float>(); a.of = dof.as<float>(); a.qdbg = nullptr;
     a.n_heads = n_heads; a.n_kv = n_kv_heads; a.hd = hd; a.seq_len = seq; a.max_chunks = max_chunks;
