@@ -9,10 +9,14 @@ weights and the KV cache already resident in HBM.  Workload: BASELINE.json's hea
 configuration, Qwen3-4B-shaped random-init Q8_0 weights (SURVEY.md 8(d) recipe), greedy
 feedback from token 9707.
 
-N > 1 (launched by torch.distributed.run, one process per GPU): the layers are split
-into N contiguous stages; the residual travels stage to stage by RCCL send/recv over
-xGMI (q3_pipeline_*), and N independent token streams keep every stage busy, so
+N > 1 (launched by torch.distributed.run, one process per GPU; RANK / WORLD_SIZE /
+LOCAL_RANK / MASTER_PORT from the environment): the layers are split into N contiguous
+stages; the residual travels stage to stage by RCCL send/recv over xGMI
+(q3_pipeline_*), and N independent greedy token streams keep every stage busy, so
 `value` = tokens/s summed over the N streams ("weak" scaling: one stream per GPU).
+The timed region is bracketed by an RCCL all-reduce (barrier) + stream sync on every
+rank and the MAX over ranks is reported.  torch is not imported: its wheel carries its
+own HIP/RCCL runtimes, which cannot share a process with the ones the library links.
 
 The JSON line also carries
   roofline      HBM roofline of the dominant kernel (the gate/up GEMV): algorithmic bytes
@@ -100,6 +104,9 @@ def main():
     args = ap.parse_args()
 
     os.environ["OMP_NUM_THREADS"] = str(host_cores())   # before libgomp is first loaded
+    # RCCL's bootstrap must stay on loopback: all ranks are on this node and the boxes'
+    # other interfaces refuse connections
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
@@ -112,32 +119,41 @@ def main():
     if hip.q3_device_count() <= 0:
         raise SystemExit("[bench] no HIP device: the product path has no CPU fallback")
 
-    dist = None
     if ngpu > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")   # control plane only: rendezvous + barriers
-        idb = bytearray(128)
+        import signal
+        signal.alarm(int(os.environ.get("Q3_BENCH_TIMEOUT", "900")))   # never hang a node: die instead
+        # Rendezvous without torch: torch's wheel bundles its own HIP/RCCL runtimes, which must
+        # not share a process with the ROCm 7.2 ones libq3hip.so links.  All ranks are on one
+        # node, so rank 0 publishes the RCCL unique id in a file keyed by MASTER_PORT.
+        port = os.environ.get("MASTER_PORT", "0")
+        idfile = os.path.join(Q.tmp_dir(), f"rccl_id_{port}_{ngpu}")
+        started = time.time()
         if rank == 0:
             buf = (C.c_char * 128)()
             assert hip.q3_pipeline_unique_id(buf) == 0
-            idb[:] = bytes(buf)
-        t = torch.tensor(list(idb), dtype=torch.uint8)
-        dist.broadcast(t, src=0)
-        raw = bytes(t.tolist())
+            with open(idfile + ".tmp", "wb") as f:
+                f.write(bytes(buf))
+            os.replace(idfile + ".tmp", idfile)
+        else:
+            while not (os.path.exists(idfile) and os.path.getmtime(idfile) > started - 30.0
+                       and os.path.getsize(idfile) == 128):
+                if time.time() - started > 300:
+                    raise SystemExit("[bench] rank 0 never published the RCCL id")
+                time.sleep(0.05)
+        raw = open(idfile, "rb").read()
         assert hip.q3_pipeline_init(rank, ngpu, raw) == 0
+        hip.q3_pipeline_allreduce_max(0.0)            # everybody has joined
+        if rank == 0:
+            os.remove(idfile)
 
     tmp = Q.tmp_dir()
     path = os.path.join(tmp, f"{args.model}.bin")
     t0 = time.perf_counter()
-    if ngpu > 1:
-        if rank == 0:
-            Q.synth(args.model, path)
-        dist.barrier()
-    else:
+    if rank == 0:
         Q.synth(args.model, path)
-    log(f"[bench] checkpoint {path} ready in {time.perf_counter() - t0:.1f}s")
+    if ngpu > 1:
+        hip.q3_pipeline_allreduce_max(0.0)            # the checkpoint is on disk
+    log(f"[bench] rank {rank}: checkpoint {path} ready in {time.perf_counter() - t0:.1f}s")
     seq = max(args.seq_len, args.context + args.steps + args.warmup + 8)
     m = hip.q3_model_open(path.encode(), seq, 0)
     assert m, "cannot open checkpoint"
@@ -167,19 +183,17 @@ def main():
         elapsed = time.perf_counter() - t0
         total_tokens = K
     else:
-        hip.q3_pipeline_run.restype = C.c_double
-        hip.q3_pipeline_run.argtypes = [Q.ModelP, C.c_int, C.c_int, C.c_int]
-        hip.q3_pipeline_run(m, START_TOKEN % vocab, pos0, W)
-        dist.barrier()
-        t0 = time.perf_counter()
-        hip.q3_pipeline_run(m, START_TOKEN % vocab, pos0 + W, K)
+        # N streams x (W + K) tokens: untimed fill + warm-up, then K timed tokens per stream
+        first = START_TOKEN % vocab
+        hip.q3_pipeline_run(m, first, pos0, W)
         hip.q3_device_sync(m)
-        local = time.perf_counter() - t0
-        import torch
-        tt = torch.tensor([local], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        hip.q3_pipeline_allreduce_max(0.0)
+        t0 = time.perf_counter()
+        hip.q3_pipeline_run(m, first, pos0 + W, K)
+        hip.q3_device_sync(m)
+        elapsed = hip.q3_pipeline_allreduce_max(time.perf_counter() - t0)
         total_tokens = K * ngpu
+        tok, pos = first, pos0 + W + K
 
     out = {
         "metric": "decode tokens/sec Qwen3-4B Q8_0" if args.model == "4B" else f"decode tokens/sec Qwen3-{args.model} Q8_0",
@@ -205,6 +219,13 @@ def main():
     out["hbm_roofline_frac_step"] = round(per_gpu_rate * bpt / 1e9 / HBM_PEAK_GBS * (1 if ngpu == 1 else 1.0), 4)
     out["bytes_per_token"] = int(bpt)
 
+    if ngpu == 1:
+        # the same decode loop kept on the device (argmax feeds the next step, no D2H per token)
+        hip.q3_pipeline_run(m, tok, pos, 8); hip.q3_device_sync(m)
+        t0 = time.perf_counter()
+        hip.q3_pipeline_run(m, tok, pos + 8, K); hip.q3_device_sync(m)
+        out["device_loop_tokens_per_s"] = round(K / (time.perf_counter() - t0), 2)
+        pos += 8 + K
     if rank == 0 and ngpu == 1 and not args.no_roofline:
         hip.q3_prof_enable(m, 1)
         hip.q3_prof_reset(m)
@@ -239,9 +260,8 @@ def main():
         except Exception as exc:   # the baseline is a reported number, never a reason to lose the line
             out["cpu_baseline"] = {"value": None, "error": repr(exc)}
     if ngpu > 1:
+        hip.q3_pipeline_allreduce_max(0.0)
         hip.q3_pipeline_shutdown()
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
 

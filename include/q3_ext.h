@@ -137,16 +137,40 @@ void q3_prof_enable(Model* m, int on);
 void q3_prof_reset(Model* m);
 int q3_prof_get(Model* m, Q3ProfEntry* out, int max_entries);
 
-/* ---- multi-GPU layer pipeline (one process per GPU) -------------------- */
+/* ---- multi-GPU layer pipeline (one process per GPU) --------------------
+ * The reference has no multi-device path; this is the layer pipeline
+ * BASELINE.json asks for.  Rank r owns a contiguous block of layers (rank 0 also the
+ * embedding, the last rank the final norm + classifier); the fp32 residual x[dim]
+ * moves from rank r to r+1, and the chosen token id from the last rank back to rank
+ * 0, by RCCL send/recv over xGMI.  `world` independent token streams travel around
+ * the ring so that every stage works on every tick (stream s, token k is on rank r at
+ * tick s + k*world + r); copying fp32 is exact, so each stream's tokens are the ones
+ * a single GPU produces. */
 #define Q3_PIPE_ID_BYTES 128
-/* Rank 0 creates the RCCL unique id; the harness broadcasts the bytes. */
+/* Rank 0 creates the RCCL unique id; the harness hands the bytes to every rank. */
 int q3_pipeline_unique_id(void* id_bytes);
-/* Join the communicator; must be called before q3_device_attach().  Stage
- * `rank` owns a contiguous block of layers (rank 0 also the embedding, the
- * last rank the final norm + classifier). */
+/* Join the communicator; must be called before q3_device_attach(). */
 int q3_pipeline_init(int rank, int world, const void* id_bytes);
 void q3_pipeline_layers(const ModelParams* p, int rank, int world, int* first, int* count);
+/* Which (stream, token index) rank `rank` handles at global tick `tick`; returns 0 when
+ * the rank is idle on that tick (pipeline fill / drain). */
+int q3_pipeline_schedule(int rank, int world, int nsteps, int tick, int* stream, int* k);
+/* Greedy-decode `nsteps` tokens of every stream on the device(s), all streams starting
+ * from `first_token` at position pos0.  Asynchronous: returns after enqueueing; follow
+ * with q3_device_sync().  With world == 1 this is the on-device greedy loop. */
+int q3_pipeline_run(Model* m, int first_token, int pos0, int nsteps);
+/* Tokens stream `stream` chose in the last q3_pipeline_run (valid on the last rank). */
+int q3_pipeline_tokens(Model* m, int stream, int* out, int n);
+/* Single-GPU self-test of the pipeline code: `world` stages in one process, hand-offs by
+ * device copies instead of RCCL.  out_tokens[world][nsteps].  Returns 0 on success. */
+int q3_pipeline_selftest(const char* path, int seq_len, int world, int first_token, int pos0,
+                         int nsteps, int* out_tokens);
+/* max over ranks (doubles as a barrier) */
+double q3_pipeline_allreduce_max(double v);
 void q3_pipeline_shutdown(void);
+
+/* diagnostic builds (-DQ3_ATTN_STAMPS, Q3_STAMPS=1): time stamps of the attention kernel */
+int q3_debug_stamps(Model* m, unsigned long long* out, int n);
 
 const char* q3_version(void);
 

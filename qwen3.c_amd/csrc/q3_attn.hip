@@ -317,4 +317,15 @@ void begin_step(const Ctl* ctl, const int8_t* eq, const float* es, int dim, floa
     hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(256), 0, st, ctl, eq, es, dim, x, rope, hd, cs);
 }
 
+
+// ctl = {token, pos} for the step about to run: the token comes from device memory when
+// the previous step's argmax (or a pipeline recv) produced it, else from the argument
+__global__ void k_set_ctl(Ctl* ctl, const int* tok_src, int tok_imm, int pos) {
+    ctl->token = tok_src ? *tok_src : tok_imm;
+    ctl->pos = pos;
+}
+void set_ctl(Ctl* ctl, const int* tok_src, int tok_imm, int pos, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, st, ctl, tok_src, tok_imm, pos);
+}
+
 }  // namespace q3k

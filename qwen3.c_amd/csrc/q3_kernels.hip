@@ -213,7 +213,7 @@ void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x,
 
 // first index of the maximum (what a strict `>` scan returns), one workgroup
 __global__ __launch_bounds__(1024) void k_argmax(const float* __restrict__ logits, int n, int* out,
-                                                 Ctl* next) {
+                                                 int* out2) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     float v = -3.4e38f;
@@ -247,14 +247,11 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* __restrict__ logit
             }
         }
         *out = idx;
-        if (next) {
-            next->token = idx;
-            next->pos = next->pos + 1;
-        }
+        if (out2) *out2 = idx;
     }
 }
-void argmax(const float* logits, int n, int* out, Ctl* ctl_next, hipStream_t st) {
-    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, n, out, ctl_next);
+void argmax(const float* logits, int n, int* out, int* out2, hipStream_t st) {
+    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, n, out, out2);
 }
 
 __global__ __launch_bounds__(64) void k_rmsnorm(float* out, const float* x, const float* w, int n) {

@@ -60,7 +60,8 @@ void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x,
 // stages) and cs = rope[ctl->pos]
 void begin_step(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, const float* rope,
                 int hd, float* cs, hipStream_t st);
-void argmax(const float* logits, int n, int* out, Ctl* ctl_next, hipStream_t st);
+void argmax(const float* logits, int n, int* out, int* out2, hipStream_t st);
+void set_ctl(Ctl* ctl, const int* tok_src, int tok_imm, int pos, hipStream_t st);
 
 // stand-alone ops behind the reference's exported symbols / the op-level tests
 void rmsnorm(float* out, const float* x, const float* w, int n, hipStream_t st);

@@ -70,6 +70,8 @@ struct Pipe {
     ncclComm_t comm = nullptr;
 };
 Pipe g_pipe;
+// stage identity for the next attach() (loopback self-test only); world 0 = use g_pipe
+struct NextStage { int rank = 0, world = 0; } g_next_stage;
 
 struct Dev {
     Model* m = nullptr;
@@ -78,6 +80,11 @@ struct Dev {
     int dim = 0, hid = 0, L = 0, H = 0, KV = 0, hd = 0, P = 0, KVD = 0, V = 0, seq = 0;
     int seq_pad = 0;             // cache rows per kv head: seq rounded up to the 64-position chunk
     int l0 = 0, l1 = 0;          // layers [l0, l1) live on this device
+    int rank = 0, world = 1;     // pipeline stage identity of this Dev
+    bool loopback = false;       // self-test: all stages in one process, hand-offs by D2D copy
+    Dev* loop_prev = nullptr;    // loopback: the stage that feeds this one (ring)
+    float* outbox[2] = {nullptr, nullptr};   // loopback mailboxes, indexed by tick parity
+    int* tokbox[2] = {nullptr, nullptr};
     bool has_embed = true, has_cls = true;
     std::vector<LayerDev> layers; // indexed by global layer id; only [l0,l1) filled
     std::vector<void*> allocs;
@@ -94,6 +101,14 @@ struct Dev {
     bool logits_pinned = false;
     bool use_graph = true;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] pos < 64, [1] chunked attention
+    // pipeline / on-device loop: one KV cache per concurrent token stream
+    int n_streams = 1;
+    size_t cache_floats = 0;      // floats of one stream's K (or V) cache of one layer
+    std::vector<hipGraphExec_t> pgexec;   // [stream*2 + multi], step without the ctl upload
+    int* tok_in = nullptr;        // token for the next step of stage 0 (argmax or recv)
+    int* tok_out = nullptr;       // last stage: argmax result to send
+    int* ptokens = nullptr;       // last stage: [n_streams][cap] chosen tokens
+    int ptokens_cap = 0;
     bool tap = false;
     std::vector<float> tap_host;
     bool prof = false;
@@ -211,10 +226,11 @@ void upload_weights(Dev* d) {
         L.qnw = upload<float>(d, w->q_rms_norm + (size_t)l * hd, hd);
         L.knw = upload<float>(d, w->k_rms_norm + (size_t)l * hd, hd);
         const size_t cache = (size_t)d->KV * d->seq_pad * hd;
-        L.kc = dalloc<float>(d, cache);
-        L.vc = dalloc<float>(d, cache);
-        HIPCHK(hipMemsetAsync(L.kc, 0, cache * 4, d->st));
-        HIPCHK(hipMemsetAsync(L.vc, 0, cache * 4, d->st));
+        d->cache_floats = cache;
+        L.kc = dalloc<float>(d, cache * d->n_streams);
+        L.vc = dalloc<float>(d, cache * d->n_streams);
+        HIPCHK(hipMemsetAsync(L.kc, 0, cache * d->n_streams * 4, d->st));
+        HIPCHK(hipMemsetAsync(L.vc, 0, cache * d->n_streams * 4, d->st));
     }
     HIPCHK(hipStreamSynchronize(d->st));
     HIPCHK(hipFree(stage_q));
@@ -263,12 +279,18 @@ Dev* attach(Model* m) {
     d->P = d->H * d->hd; d->KVD = d->KV * d->hd;
     d->seq_pad = (d->seq + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK * Q3_ATT_CHUNK;
     d->l0 = 0; d->l1 = d->L;
-    if (g_pipe.on) {
+    if (g_next_stage.world > 0) {
+        d->rank = g_next_stage.rank; d->world = g_next_stage.world; d->loopback = true;
+    } else if (g_pipe.on) {
+        d->rank = g_pipe.rank; d->world = g_pipe.world;
+    }
+    if (d->world > 1) {
         int first, count;
-        pipeline_split(d->L, g_pipe.rank, g_pipe.world, &first, &count);
+        pipeline_split(d->L, d->rank, d->world, &first, &count);
         d->l0 = first; d->l1 = first + count;
-        d->has_embed = g_pipe.rank == 0;
-        d->has_cls = g_pipe.rank == g_pipe.world - 1;
+        d->has_embed = d->rank == 0;
+        d->has_cls = d->rank == d->world - 1;
+        d->n_streams = d->world;
     }
     const char* eg = getenv("Q3_GRAPH");
     d->use_graph = !(eg && eg[0] == '0');
@@ -289,6 +311,15 @@ Dev* attach(Model* m) {
     d->tap_dev = dalloc<float>(d, (size_t)d->L * d->dim);
     d->ctl = dalloc<q3k::Ctl>(d, 1);
     d->amax = dalloc<int>(d, 1);
+    d->tok_in = dalloc<int>(d, 1);
+    d->tok_out = dalloc<int>(d, 1);
+    if (d->loopback) {
+        for (int i = 0; i < 2; i++) {
+            d->outbox[i] = dalloc<float>(d, d->dim);
+            d->tokbox[i] = dalloc<int>(d, 1);
+        }
+    }
+    d->pgexec.assign((size_t)d->n_streams * 2, nullptr);
     if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 64); HIPCHK(hipMemset(d->stamps, 0, 64 * 8)); }
     HIPCHK(hipHostMalloc((void**)&d->ctl_host, sizeof(q3k::Ctl), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&d->amax_host, sizeof(int), hipHostMallocDefault));
@@ -369,17 +400,17 @@ void prof_collect(Dev* d) {
 
 // ---- the decode step --------------------------------------------------------
 
-q3k::Attn attn_args(Dev* d, int l) {
+q3k::Attn attn_args(Dev* d, int l, int stream = 0) {
     const LayerDev& L = d->layers[l];
     q3k::Attn a;
     a.ctl = d->ctl; a.qkv = d->qkv; a.qnw = L.qnw; a.knw = L.knw; a.cs = d->cs_cur;
-    a.kc = L.kc; a.vc = L.vc; a.part = d->part; a.oq = d->att_q; a.os = d->att_s;
+    a.kc = L.kc + (size_t)stream * d->cache_floats; a.vc = L.vc + (size_t)stream * d->cache_floats; a.part = d->part; a.oq = d->att_q; a.os = d->att_s;
     a.of = nullptr; a.qdbg = nullptr; a.prepared = 0; a.stamps = d->stamps;
     a.n_heads = d->H; a.n_kv = d->KV; a.hd = d->hd; a.seq_len = d->seq_pad; a.max_chunks = d->max_chunks;
     return a;
 }
 
-void enqueue_layer(Dev* d, int l, bool multi) {
+void enqueue_layer(Dev* d, int l, bool multi, int stream = 0) {
     const LayerDev& L = d->layers[l];
     q3k::Gemv g;
     memset(&g, 0, sizeof(g));
@@ -390,7 +421,7 @@ void enqueue_layer(Dev* d, int l, bool multi) {
         q3k::gemv(g, q3k::PRO_NORM, q3k::EPI_STORE, d->st);
     }
     {   // head norms + RoPE + cache append + attention + quantise (forward.c:267-291)
-        q3k::Attn a = attn_args(d, l);
+        q3k::Attn a = attn_args(d, l, stream);
         Timed t(d, "attn", 0.0);
         q3k::attn(a, multi ? d->chunk_slots : 1, multi, d->st);
         if (multi) q3k::attn_combine(a, d->st);
@@ -429,13 +460,13 @@ void enqueue_head(Dev* d) {
 }
 
 // everything of one step that runs on this device, between the ctl upload and the logits
-void enqueue_step(Dev* d, bool multi) {
+void enqueue_step(Dev* d, bool multi, int stream = 0) {
     {
         Timed t(d, "begin", 0.0);
         q3k::begin_step(d->ctl, d->has_embed ? d->emb_q : nullptr, d->emb_s, d->dim, d->x, d->rope, d->hd,
                         d->cs_cur, d->st);
     }
-    for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, multi);
+    for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, multi, stream);
     if (d->has_cls) enqueue_head(d);
 }
 
@@ -465,7 +496,7 @@ void check_step_args(Dev* d, int token, int pos) {
 void run_step(Dev* d, int token, int pos, bool to_host) {
     check_step_args(d, token, pos);
     HIPCHK(hipSetDevice(d->device));
-    if (g_pipe.on && g_pipe.world > 1) Q3_DIE("pipeline step must go through q3_pipeline_step");
+    if (d->world > 1) Q3_DIE("this Model is one stage of a %d-stage pipeline: use q3_pipeline_run()", d->world);
     const bool multi = pos >= Q3_ATT_CHUNK;
     d->ctl_host->token = token;
     d->ctl_host->pos = pos;
@@ -582,6 +613,9 @@ void q3_device_detach(Model* m) {
     for (auto& ex : d->gexec) {
         if (ex) (void)hipGraphExecDestroy(ex);
     }
+    for (auto& ex : d->pgexec) {
+        if (ex) (void)hipGraphExecDestroy(ex);
+    }
     for (auto& pr : d->ev_pool) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
@@ -625,14 +659,144 @@ int q3_device_argmax(Model* m) {
     return *d->amax_host;
 }
 
+}  // extern "C"
+
+namespace {
+
+// ---- on-device token loop and layer pipeline ---------------------------------------
+//
+// N ranks (one process per GPU) each own a contiguous block of layers; N independent
+// token streams travel around the ring so that every stage is busy on every tick:
+// stream s, token k sits on rank r at tick t = s + k*N + r.  Hand-offs are RCCL
+// point-to-point over xGMI: the fp32 residual x[dim] from rank r to r+1, and the chosen
+// token id from the last rank back to rank 0.  With N = 1 the same loop is the
+// on-device greedy decoder (no host round trip per token).
+
+void ensure_token_log(Dev* d, int per_stream) {
+    if (per_stream <= d->ptokens_cap) return;
+    d->ptokens = dalloc<int>(d, (size_t)per_stream * d->n_streams);
+    d->ptokens_cap = per_stream;
+}
+
+__global__ void k_log_token(const int* tok, int* log_slot) { *log_slot = *tok; }
+
+void launch_stage(Dev* d, bool multi, int stream) {
+    const bool pinned_ok = true;
+    if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
+        hipGraphExec_t& ex = d->pgexec[(size_t)stream * 2 + (multi ? 1 : 0)];
+        if (!ex) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(d->st, hipStreamCaptureModeThreadLocal));
+            enqueue_step(d, multi, stream);
+            HIPCHK(hipStreamEndCapture(d->st, &graph));
+            HIPCHK(hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0));
+            HIPCHK(hipGraphDestroy(graph));
+        }
+        HIPCHK(hipGraphLaunch(ex, d->st));
+    } else {
+        enqueue_step(d, multi, stream);
+    }
+}
+
+#define NCCLCHK(expr)                                                                   \
+    do {                                                                                \
+        ncclResult_t r_ = (expr);                                                       \
+        if (r_ != ncclSuccess) Q3_DIE("%s failed: %s", #expr, ncclGetErrorString(r_)); \
+    } while (0)
+
+// hand-offs of one stage: RCCL point-to-point between processes, or (loopback self-test)
+// stream-ordered device copies between the stages of one process
+// (a message sent on tick t is received on tick t+1: the loopback mailboxes are indexed
+// by tick parity so that the order in which one process walks its stages does not matter)
+void recv_x(Dev* d, int tick) {
+    if (d->loopback) HIPCHK(hipMemcpyAsync(d->x, d->loop_prev->outbox[(tick + 1) & 1], (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
+    else NCCLCHK(ncclRecv(d->x, (size_t)d->dim, ncclFloat32, d->rank - 1, g_pipe.comm, d->st));
+}
+void send_x(Dev* d, int tick) {
+    if (d->loopback) HIPCHK(hipMemcpyAsync(d->outbox[tick & 1], d->x, (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
+    else NCCLCHK(ncclSend(d->x, (size_t)d->dim, ncclFloat32, d->rank + 1, g_pipe.comm, d->st));
+}
+void recv_tok(Dev* d, int tick) {
+    if (d->loopback) HIPCHK(hipMemcpyAsync(d->tok_in, d->loop_prev->tokbox[(tick + 1) & 1], sizeof(int), hipMemcpyDeviceToDevice, d->st));
+    else NCCLCHK(ncclRecv(d->tok_in, 1, ncclInt32, d->world - 1, g_pipe.comm, d->st));
+}
+void send_tok(Dev* d, int tick) {
+    if (d->loopback) HIPCHK(hipMemcpyAsync(d->tokbox[tick & 1], d->tok_out, sizeof(int), hipMemcpyDeviceToDevice, d->st));
+    else NCCLCHK(ncclSend(d->tok_out, 1, ncclInt32, 0, g_pipe.comm, d->st));
+}
+
+// One tick of one stage (q3_pipeline_schedule says which stream / token it works on).
+void pipeline_tick(Dev* d, int first_token, int pos0, int nsteps, int tick, int s, int k) {
+    const int N = d->world, r = d->rank;
+    const int pos = pos0 + k;
+    const bool last = r == N - 1;
+    HIPCHK(hipSetDevice(d->device));
+    if (r == 0) {
+        if (k > 0 && N > 1) recv_tok(d, tick);
+        q3k::set_ctl(d->ctl, k > 0 ? d->tok_in : nullptr, first_token, pos, d->st);
+    } else {
+        recv_x(d, tick);
+        q3k::set_ctl(d->ctl, nullptr, 0, pos, d->st);
+    }
+    launch_stage(d, pos >= Q3_ATT_CHUNK, s);
+    if (!last) {
+        send_x(d, tick);
+    } else {
+        // greedy pick on the device; with one stage it feeds the next step directly
+        int* dst = N == 1 ? d->tok_in : d->tok_out;
+        q3k::argmax(d->logits, d->V, dst, nullptr, d->st);
+        hipLaunchKernelGGL(k_log_token, dim3(1), dim3(1), 0, d->st, dst, d->ptokens + (size_t)s * d->ptokens_cap + k);
+        if (N > 1 && k < nsteps - 1) send_tok(d, tick);
+    }
+}
+
+void pipeline_check(Dev* d, int first_token, int pos0, int nsteps) {
+    if (pos0 < 0 || nsteps < 0 || pos0 + nsteps > d->seq) Q3_DIE("pipeline_run: positions [%d,%d) outside the window %d", pos0, pos0 + nsteps, d->seq);
+    if (first_token < 0 || first_token >= d->V) Q3_DIE("pipeline_run: bad first token %d", first_token);
+    if (d->rank == d->world - 1) ensure_token_log(d, nsteps);
+}
+
+// Runs `nsteps` tokens of every stream, starting from `first_token` at `pos0`.
+// Returns the number of ticks this rank executed.
+int pipeline_run(Dev* d, int first_token, int pos0, int nsteps) {
+    pipeline_check(d, first_token, pos0, nsteps);
+    int ticks = 0;
+    for (int t = 0; t < nsteps * d->world + d->world - 1; t++) {
+        int s = 0, k = 0;
+        if (!q3_pipeline_schedule(d->rank, d->world, nsteps, t, &s, &k)) continue;
+        pipeline_tick(d, first_token, pos0, nsteps, t, s, k);
+        ticks++;
+    }
+    return ticks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int q3_pipeline_run(Model* m, int first_token, int pos0, int nsteps) {
+    Dev* d = attach(m);
+    return pipeline_run(d, first_token, pos0, nsteps);
+}
+
+// Tokens chosen by stream `stream` in the last q3_pipeline_run (valid on the last rank).
+int q3_pipeline_tokens(Model* m, int stream, int* out, int n) {
+    Dev* d = attach(m);
+    if (!d->ptokens || stream < 0 || stream >= d->n_streams) return 0;
+    if (n > d->ptokens_cap) n = d->ptokens_cap;
+    HIPCHK(hipStreamSynchronize(d->st));
+    HIPCHK(hipMemcpy(out, d->ptokens + (size_t)stream * d->ptokens_cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    return n;
+}
+
 int q3_generate_greedy(Model* m, int token, int pos, int n, int* out_tokens) {
     Dev* d = attach(m);
-    for (int i = 0; i < n; i++) {
-        if (pos + i >= d->seq) return i;
-        run_step(d, token, pos + i, i == n - 1);
-        token = q3_device_argmax(m);
-        if (out_tokens) out_tokens[i] = token;
-    }
+    if (d->world > 1) Q3_DIE("q3_generate_greedy: use q3_pipeline_run on a pipeline");
+    if (pos + n > d->seq) n = d->seq - pos;
+    if (n <= 0) return 0;
+    pipeline_run(d, token, pos, n);
+    if (out_tokens) q3_pipeline_tokens(m, 0, out_tokens, n);
+    q3_logits_fetch(m);
     return n;
 }
 
@@ -874,7 +1038,59 @@ void q3_pipeline_layers(const ModelParams* p, int rank, int world, int* first, i
     pipeline_split(p->n_layers, rank, world, first, count);
 }
 
+// Self-test of the pipeline code on ONE GPU: `world` stages of the same checkpoint live in
+// this process (each uploads only its own layers), ticks are executed in the order the
+// schedule prescribes, and the RCCL hand-offs are replaced by stream-ordered device
+// copies.  Everything else -- layer split, per-stream KV caches, tick schedule, token
+// feedback, graphs -- is the code the multi-process run executes.
+// out_tokens[world][nsteps]; returns 0 on success.
+int q3_pipeline_selftest(const char* path, int seq_len, int world, int first_token, int pos0, int nsteps,
+                         int* out_tokens) {
+    if (world < 1 || world > 64) return -1;
+    std::vector<Model*> ms(world, nullptr);
+    std::vector<Dev*> ds(world, nullptr);
+    for (int r = 0; r < world; r++) {
+        ms[r] = q3_model_open(path, seq_len, 0);
+        if (!ms[r]) return -1;
+        g_next_stage.rank = r;
+        g_next_stage.world = world;
+        ds[r] = attach(ms[r]);
+        g_next_stage.world = 0;
+    }
+    for (int r = 0; r < world; r++) {
+        ds[r]->loop_prev = ds[(r + world - 1) % world];
+        // one stream for all stages: program order = tick order = data dependencies
+        if (r > 0) {
+            HIPCHK(hipStreamDestroy(ds[r]->st));
+            ds[r]->st = ds[0]->st;
+        }
+        pipeline_check(ds[r], first_token, pos0, nsteps);
+    }
+    for (int t = 0; t < nsteps * world + world - 1; t++) {
+        for (int r = 0; r < world; r++) {
+            int s = 0, k = 0;
+            if (q3_pipeline_schedule(r, world, nsteps, t, &s, &k)) pipeline_tick(ds[r], first_token, pos0, nsteps, t, s, k);
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ds[0]->st));
+    for (int s = 0; s < world; s++) q3_pipeline_tokens(ms[world - 1], s, out_tokens + (size_t)s * nsteps, nsteps);
+    for (int r = world - 1; r >= 0; r--) {
+        if (r > 0) HIPCHK(hipStreamCreateWithFlags(&ds[r]->st, hipStreamNonBlocking));   // detach destroys it
+        q3_model_close(ms[r]);
+    }
+    return 0;
+}
+
+int q3_pipeline_schedule(int rank, int world, int nsteps, int tick, int* stream, int* k) {
+    const int u = tick - rank;
+    if (u < 0 || u >= nsteps * world) return 0;
+    if (stream) *stream = u % world;
+    if (k) *k = u / world;
+    return 1;
+}
+
 int q3_pipeline_unique_id(void* id_bytes) {
+    setenv("NCCL_SOCKET_IFNAME", "lo", 0);   // single-node pipeline: bootstrap over loopback
     ncclUniqueId id;
     if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
     memset(id_bytes, 0, Q3_PIPE_ID_BYTES);
@@ -890,6 +1106,7 @@ int q3_pipeline_init(int rank, int world, const void* id_bytes) {
     g_pipe.world = world;
     g_pipe.on = world > 1;
     if (world > 1) {
+        setenv("NCCL_SOCKET_IFNAME", "lo", 0);
         ncclUniqueId id;
         memcpy(&id, id_bytes, sizeof(id));
         ncclResult_t r = ncclCommInitRank(&g_pipe.comm, world, id, rank);
@@ -899,6 +1116,20 @@ int q3_pipeline_init(int rank, int world, const void* id_bytes) {
         }
     }
     return 0;
+}
+
+// max over ranks of a host double (also serves as a barrier); identity on one rank
+double q3_pipeline_allreduce_max(double v) {
+    if (!g_pipe.on || g_pipe.world <= 1) return v;
+    double* dv = nullptr;
+    HIPCHK(hipMalloc((void**)&dv, sizeof(double)));
+    HIPCHK(hipMemcpy(dv, &v, sizeof(double), hipMemcpyHostToDevice));
+    ncclResult_t r = ncclAllReduce(dv, dv, 1, ncclFloat64, ncclMax, g_pipe.comm, nullptr);
+    if (r != ncclSuccess) Q3_DIE("ncclAllReduce failed: %s", ncclGetErrorString(r));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(hipMemcpy(&v, dv, sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(dv));
+    return v;
 }
 
 void q3_pipeline_shutdown(void) {

@@ -201,6 +201,18 @@ def hip_lib():
         lib.q3_pipeline_init.argtypes = [C.c_int, C.c_int, C.c_void_p]
         lib.q3_pipeline_layers.restype = None
         lib.q3_pipeline_layers.argtypes = [C.POINTER(ModelParams), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.q3_pipeline_schedule.restype = C.c_int
+        lib.q3_pipeline_schedule.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.q3_pipeline_run.restype = C.c_int
+        lib.q3_pipeline_run.argtypes = [ModelP, C.c_int, C.c_int, C.c_int]
+        lib.q3_pipeline_tokens.restype = C.c_int
+        lib.q3_pipeline_tokens.argtypes = [ModelP, C.c_int, C.POINTER(C.c_int), C.c_int]
+        lib.q3_pipeline_selftest.restype = C.c_int
+        lib.q3_pipeline_selftest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        lib.q3_pipeline_allreduce_max.restype = C.c_double
+        lib.q3_pipeline_allreduce_max.argtypes = [C.c_double]
+        lib.q3_debug_stamps.restype = C.c_int
+        lib.q3_debug_stamps.argtypes = [ModelP, C.POINTER(C.c_uint64), C.c_int]
         lib.q3_pipeline_shutdown.restype = None
         lib.q3_version.restype = C.c_char_p
         _cache["hip"] = lib

@@ -105,3 +105,38 @@ def test_device_argmax_and_greedy_loop(hip, host):
     assert hip.q3_generate_greedy(mg, 7, 0, 20, out) == 20
     assert list(out) == toks
     hip.q3_model_close(mg); host.q3_model_close(_mo)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_pipeline_selftest_matches_single_gpu(hip, host, world):
+    """The layer pipeline (stage split, per-stream KV caches, tick schedule, token feedback)
+    run as `world` stages on this one GPU, with device copies in place of the RCCL
+    hand-offs: every stream must reproduce the single-GPU greedy tokens exactly."""
+    path = os.path.join(Q.tmp_dir(), "small.bin")
+    Q.synth("small", path)
+    mg = hip.q3_model_open(path.encode(), 0, 0)
+    nsteps = 70            # crosses the 64-position chunk boundary
+    want = (C.c_int * nsteps)()
+    assert hip.q3_generate_greedy(mg, 7, 0, nsteps, want) == nsteps
+    hip.q3_model_close(mg)
+    got = (C.c_int * (world * nsteps))()
+    assert hip.q3_pipeline_selftest(path.encode(), 0, world, 7, 0, nsteps, got) == 0
+    for s in range(world):
+        assert list(got[s * nsteps:(s + 1) * nsteps]) == list(want), f"stream {s}"
+
+
+def test_pipeline_schedule_covers_every_token_once(hip):
+    for world in (1, 2, 4, 8):
+        nsteps = 5
+        seen = {}
+        for tick in range(nsteps * world + world - 1):
+            for r in range(world):
+                s, k = C.c_int(), C.c_int()
+                if hip.q3_pipeline_schedule(r, world, nsteps, tick, C.byref(s), C.byref(k)):
+                    seen.setdefault((s.value, k.value), []).append((tick, r))
+        assert len(seen) == world * nsteps
+        for (s, k), visits in seen.items():
+            # each token of each stream visits ranks 0..world-1 on consecutive ticks
+            assert [r for _, r in visits] == list(range(world))
+            assert [t for t, _ in visits] == list(range(visits[0][0], visits[0][0] + world))
+            assert visits[0][0] == s + k * world
