@@ -84,12 +84,12 @@ struct Dev {
     bool loopback = false;       // self-test: all stages in one process, hand-offs by D2D copy
     Dev* loop_prev = nullptr;    // loopback: the stage that feeds this one (ring)
     float* outbox[2] = {nullptr, nullptr};   // loopback mailboxes, indexed by tick parity
-    int* tokbox[2] = {nullptr, nullptr};
     bool has_embed = true, has_cls = true;
     std::vector<LayerDev> layers; // indexed by global layer id; only [l0,l1) filled
     std::vector<void*> allocs;
     int8_t *emb_q = nullptr, *cls_q = nullptr, *att_q = nullptr;
     float *emb_s = nullptr, *cls_s = nullptr, *out_nw = nullptr;
+    float *xout = nullptr;       // pipeline: outgoing message (residual + token slot)
     float *x = nullptr, *qkv = nullptr, *h = nullptr, *logits = nullptr, *att_s = nullptr;
     float *att_f = nullptr, *part = nullptr, *rope = nullptr, *tap_dev = nullptr, *cs_cur = nullptr;
     q3k::Ctl* ctl = nullptr;
@@ -105,8 +105,6 @@ struct Dev {
     int n_streams = 1;
     size_t cache_floats = 0;      // floats of one stream's K (or V) cache of one layer
     std::vector<hipGraphExec_t> pgexec;   // [stream*2 + multi], step without the ctl upload
-    int* tok_in = nullptr;        // token for the next step of stage 0 (argmax or recv)
-    int* tok_out = nullptr;       // last stage: argmax result to send
     int* ptokens = nullptr;       // last stage: [n_streams][cap] chosen tokens
     int ptokens_cap = 0;
     bool tap = false;
@@ -253,9 +251,10 @@ void upload_weights(Dev* d) {
 }
 
 void pipeline_split(int L, int rank, int world, int* first, int* count) {
-    const int base = L / world, rem = L % world;
-    *count = base + (rank < rem ? 1 : 0);
-    *first = rank * base + (rank < rem ? rank : rem);
+    ModelParams p;
+    memset(&p, 0, sizeof(p));
+    p.n_layers = L;
+    q3_pipeline_layers(&p, rank, world, first, count);
 }
 
 Dev* attach(Model* m) {
@@ -297,7 +296,9 @@ Dev* attach(Model* m) {
 
     upload_weights(d);
     build_rope(d);
-    d->x = dalloc<float>(d, d->dim);
+    d->x = dalloc<float>(d, d->dim + 1);      // + the token slot of pipeline messages
+    d->xout = dalloc<float>(d, d->dim + 1);
+    HIPCHK(hipMemsetAsync(d->xout, 0, ((size_t)d->dim + 1) * 4, d->st));
     d->qkv = dalloc<float>(d, d->P + 2 * d->KVD);
     d->h = dalloc<float>(d, d->hid);
     d->logits = dalloc<float>(d, d->V);
@@ -311,13 +312,8 @@ Dev* attach(Model* m) {
     d->tap_dev = dalloc<float>(d, (size_t)d->L * d->dim);
     d->ctl = dalloc<q3k::Ctl>(d, 1);
     d->amax = dalloc<int>(d, 1);
-    d->tok_in = dalloc<int>(d, 1);
-    d->tok_out = dalloc<int>(d, 1);
     if (d->loopback) {
-        for (int i = 0; i < 2; i++) {
-            d->outbox[i] = dalloc<float>(d, d->dim);
-            d->tokbox[i] = dalloc<int>(d, 1);
-        }
+        for (int i = 0; i < 2; i++) d->outbox[i] = dalloc<float>(d, d->dim + 1);
     }
     d->pgexec.assign((size_t)d->n_streams * 2, nullptr);
     if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 64); HIPCHK(hipMemset(d->stamps, 0, 64 * 8)); }
@@ -704,49 +700,46 @@ void launch_stage(Dev* d, bool multi, int stream) {
         if (r_ != ncclSuccess) Q3_DIE("%s failed: %s", #expr, ncclGetErrorString(r_)); \
     } while (0)
 
-// hand-offs of one stage: RCCL point-to-point between processes, or (loopback self-test)
-// stream-ordered device copies between the stages of one process
-// (a message sent on tick t is received on tick t+1: the loopback mailboxes are indexed
-// by tick parity so that the order in which one process walks its stages does not matter)
-void recv_x(Dev* d, int tick) {
-    if (d->loopback) HIPCHK(hipMemcpyAsync(d->x, d->loop_prev->outbox[(tick + 1) & 1], (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
-    else NCCLCHK(ncclRecv(d->x, (size_t)d->dim, ncclFloat32, d->rank - 1, g_pipe.comm, d->st));
+// Ring exchange at the end of a tick: EVERY rank sends one message (x[dim] + the token
+// slot) to its successor and receives one from its predecessor, inside one RCCL group,
+// so the hand-off is deadlock-free whatever the transport's buffering is.  Ranks that
+// have nothing to say during pipeline fill/drain send a stale buffer the receiver ignores.
+// Loopback self-test: the same exchange through device mailboxes indexed by tick parity.
+void ring_exchange(Dev* d, int tick) {
+    const size_t n = (size_t)d->dim + 1;
+    if (d->loopback) {
+        HIPCHK(hipMemcpyAsync(d->outbox[tick & 1], d->xout, n * 4, hipMemcpyDeviceToDevice, d->st));
+        return;
+    }
+    const int next = (d->rank + 1) % d->world, prev = (d->rank + d->world - 1) % d->world;
+    NCCLCHK(ncclGroupStart());
+    NCCLCHK(ncclSend(d->xout, n, ncclFloat32, next, g_pipe.comm, d->st));
+    NCCLCHK(ncclRecv(d->x, n, ncclFloat32, prev, g_pipe.comm, d->st));
+    NCCLCHK(ncclGroupEnd());
 }
-void send_x(Dev* d, int tick) {
-    if (d->loopback) HIPCHK(hipMemcpyAsync(d->outbox[tick & 1], d->x, (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
-    else NCCLCHK(ncclSend(d->x, (size_t)d->dim, ncclFloat32, d->rank + 1, g_pipe.comm, d->st));
-}
-void recv_tok(Dev* d, int tick) {
-    if (d->loopback) HIPCHK(hipMemcpyAsync(d->tok_in, d->loop_prev->tokbox[(tick + 1) & 1], sizeof(int), hipMemcpyDeviceToDevice, d->st));
-    else NCCLCHK(ncclRecv(d->tok_in, 1, ncclInt32, d->world - 1, g_pipe.comm, d->st));
-}
-void send_tok(Dev* d, int tick) {
-    if (d->loopback) HIPCHK(hipMemcpyAsync(d->tokbox[tick & 1], d->tok_out, sizeof(int), hipMemcpyDeviceToDevice, d->st));
-    else NCCLCHK(ncclSend(d->tok_out, 1, ncclInt32, 0, g_pipe.comm, d->st));
+void loopback_deliver(Dev* d, int tick) {   // what the recv half of the exchange does
+    HIPCHK(hipMemcpyAsync(d->x, d->loop_prev->outbox[tick & 1], ((size_t)d->dim + 1) * 4, hipMemcpyDeviceToDevice, d->st));
 }
 
-// One tick of one stage (q3_pipeline_schedule says which stream / token it works on).
-void pipeline_tick(Dev* d, int first_token, int pos0, int nsteps, int tick, int s, int k) {
+// The compute half of one tick of one stage (q3_pipeline_schedule says which stream /
+// token it works on).  The incoming message sits in d->x: the residual for ranks > 0,
+// the token chosen by the last rank (slot x[dim]) for rank 0.
+void pipeline_tick(Dev* d, int first_token, int pos0, int s, int k) {
     const int N = d->world, r = d->rank;
     const int pos = pos0 + k;
     const bool last = r == N - 1;
+    int* tok_slot_in = reinterpret_cast<int*>(d->x + d->dim);
+    int* tok_slot_out = reinterpret_cast<int*>(d->xout + d->dim);
     HIPCHK(hipSetDevice(d->device));
-    if (r == 0) {
-        if (k > 0 && N > 1) recv_tok(d, tick);
-        q3k::set_ctl(d->ctl, k > 0 ? d->tok_in : nullptr, first_token, pos, d->st);
-    } else {
-        recv_x(d, tick);
-        q3k::set_ctl(d->ctl, nullptr, 0, pos, d->st);
-    }
+    q3k::set_ctl(d->ctl, (r == 0 && k > 0) ? tok_slot_in : nullptr, r == 0 ? first_token : 0, pos, d->st);
     launch_stage(d, pos >= Q3_ATT_CHUNK, s);
     if (!last) {
-        send_x(d, tick);
+        HIPCHK(hipMemcpyAsync(d->xout, d->x, (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
     } else {
         // greedy pick on the device; with one stage it feeds the next step directly
-        int* dst = N == 1 ? d->tok_in : d->tok_out;
+        int* dst = N == 1 ? tok_slot_in : tok_slot_out;
         q3k::argmax(d->logits, d->V, dst, nullptr, d->st);
         hipLaunchKernelGGL(k_log_token, dim3(1), dim3(1), 0, d->st, dst, d->ptokens + (size_t)s * d->ptokens_cap + k);
-        if (N > 1 && k < nsteps - 1) send_tok(d, tick);
     }
 }
 
@@ -757,15 +750,18 @@ void pipeline_check(Dev* d, int first_token, int pos0, int nsteps) {
 }
 
 // Runs `nsteps` tokens of every stream, starting from `first_token` at `pos0`.
-// Returns the number of ticks this rank executed.
+// Returns the number of ticks on which this rank computed.
 int pipeline_run(Dev* d, int first_token, int pos0, int nsteps) {
     pipeline_check(d, first_token, pos0, nsteps);
     int ticks = 0;
-    for (int t = 0; t < nsteps * d->world + d->world - 1; t++) {
+    const int T = nsteps * d->world + d->world - 1;
+    for (int t = 0; t < T; t++) {
         int s = 0, k = 0;
-        if (!q3_pipeline_schedule(d->rank, d->world, nsteps, t, &s, &k)) continue;
-        pipeline_tick(d, first_token, pos0, nsteps, t, s, k);
-        ticks++;
+        if (q3_pipeline_schedule(d->rank, d->world, nsteps, t, &s, &k)) {
+            pipeline_tick(d, first_token, pos0, s, k);
+            ticks++;
+        }
+        if (d->world > 1 && t < T - 1) ring_exchange(d, t);
     }
     return ticks;
 }
@@ -1034,10 +1030,6 @@ void q3_op_expf(const float* x, int n, float* out) {
 
 // ---- pipeline (filled in by q3_pipeline.hip-style code below) --------------------
 
-void q3_pipeline_layers(const ModelParams* p, int rank, int world, int* first, int* count) {
-    pipeline_split(p->n_layers, rank, world, first, count);
-}
-
 // Self-test of the pipeline code on ONE GPU: `world` stages of the same checkpoint live in
 // this process (each uploads only its own layers), ticks are executed in the order the
 // schedule prescribes, and the RCCL hand-offs are replaced by stream-ordered device
@@ -1066,10 +1058,15 @@ int q3_pipeline_selftest(const char* path, int seq_len, int world, int first_tok
         }
         pipeline_check(ds[r], first_token, pos0, nsteps);
     }
-    for (int t = 0; t < nsteps * world + world - 1; t++) {
+    const int T = nsteps * world + world - 1;
+    for (int t = 0; t < T; t++) {
         for (int r = 0; r < world; r++) {
             int s = 0, k = 0;
-            if (q3_pipeline_schedule(r, world, nsteps, t, &s, &k)) pipeline_tick(ds[r], first_token, pos0, nsteps, t, s, k);
+            if (q3_pipeline_schedule(r, world, nsteps, t, &s, &k)) pipeline_tick(ds[r], first_token, pos0, s, k);
+        }
+        if (t < T - 1) {
+            for (int r = 0; r < world; r++) ring_exchange(ds[r], t);     // sends
+            for (int r = 0; r < world; r++) loopback_deliver(ds[r], t);  // receives
         }
     }
     HIPCHK(hipStreamSynchronize(ds[0]->st));
@@ -1079,14 +1076,6 @@ int q3_pipeline_selftest(const char* path, int seq_len, int world, int first_tok
         q3_model_close(ms[r]);
     }
     return 0;
-}
-
-int q3_pipeline_schedule(int rank, int world, int nsteps, int tick, int* stream, int* k) {
-    const int u = tick - rank;
-    if (u < 0 || u >= nsteps * world) return 0;
-    if (stream) *stream = u % world;
-    if (k) *k = u / world;
-    return 1;
 }
 
 int q3_pipeline_unique_id(void* id_bytes) {

@@ -232,3 +232,25 @@ double q3_bytes_per_token(const ModelParams* p, int T) {
     const double emb = dim * (1.0 + 4.0 / Q3_GROUP);
     return mat + norms + kv + emb;
 }
+
+/* ---- layer pipeline: who owns which layers, who works on what, when ------------------
+ * Pure arithmetic, kept on the host side so that harnesses and CPU tests can use it
+ * without loading the HIP runtime. */
+
+/* contiguous blocks of n_layers/world layers, the first n_layers%world ranks one more */
+void q3_pipeline_layers(const ModelParams* p, int rank, int world, int* first, int* count) {
+    const int L = p->n_layers;
+    const int base = L / world, rem = L % world;
+    *count = base + (rank < rem ? 1 : 0);
+    *first = rank * base + (rank < rem ? rank : rem);
+}
+
+/* `world` token streams circulate so that every stage is busy on every tick:
+ * stream s, token k is on rank r at tick s + k*world + r. */
+int q3_pipeline_schedule(int rank, int world, int nsteps, int tick, int* stream, int* k) {
+    const int u = tick - rank;
+    if (u < 0 || u >= nsteps * world) return 0;
+    if (stream) *stream = u % world;
+    if (k) *k = u / world;
+    return 1;
+}

@@ -101,6 +101,10 @@ def _bind_host(lib):
     lib.q3_bytes_per_token.argtypes = [C.POINTER(ModelParams), C.c_int]
     lib.q3_gemv_bytes.restype = C.c_double
     lib.q3_gemv_bytes.argtypes = [C.c_int, C.c_int]
+    lib.q3_pipeline_layers.restype = None
+    lib.q3_pipeline_layers.argtypes = [C.POINTER(ModelParams), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.q3_pipeline_schedule.restype = C.c_int
+    lib.q3_pipeline_schedule.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return lib
 
 
