@@ -72,3 +72,23 @@ def test_no_cpu_fallback_without_a_gpu():
     assert p.returncode != 0
     assert "COMPUTED" not in p.stdout
     assert "[q3hip]" in p.stderr and "no CPU path" in p.stderr
+
+
+def test_reference_links_against_the_library_without_forward_c():
+    """The drop-in claim of INTEGRATION.md section 1, at link time: the reference's other six
+    translation units link into a complete shared object when src/forward.c and src/q8.c
+    are replaced by -lq3hip (no undefined symbols allowed)."""
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "src", "forward.c")):
+        import pytest
+        pytest.skip("reference tree not present on this machine")
+    srcs = [os.path.join(ref, "src", f + ".c") for f in ("xorshift", "tokenizer", "model", "sampler", "qwen", "completion")]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "libqwen3_gpu.so")
+        cmd = ["gcc", "-std=gnu17", "-DNDEBUG", "-O2", "-Wno-unused-result", "-I" + os.path.join(ref, "include"),
+               "-fPIC", "-shared"] + srcs + ["-L" + Q.PKG, "-lq3hip", "-Wl,-rpath," + Q.PKG, "-Wl,--no-undefined",
+                                             "-lm", "-o", out]
+        subprocess.check_call(cmd)
+        syms = subprocess.check_output(["nm", "-D", "--undefined-only", out], text=True)
+        for name in ("forward", "softmax", "q8_dequantize"):
+            assert re.search(r"\bU %s\b" % name, syms), name      # resolved from libq3hip.so

@@ -140,3 +140,24 @@ def test_pipeline_schedule_covers_every_token_once(hip):
             assert [r for _, r in visits] == list(range(world))
             assert [t for t, _ in visits] == list(range(visits[0][0], visits[0][0] + world))
             assert visits[0][0] == s + k * world
+
+
+def test_model_created_by_the_reference_loader_is_accepted(hip, host, orc):
+    """forward() on a Model that the REFERENCE's model_create() built (oracle/_ref, compiled from
+    /root/reference): same struct layout, weights read through its mmap views."""
+    ref = Q.reference_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref not available")
+    path = os.path.join(Q.tmp_dir(), "small.bin")
+    Q.synth("small", path)
+    mr = ref.model_create(path.encode(), 0)
+    mo = host.q3_model_open(path.encode(), 0, 1)
+    orc.orc_set_mode(Q.ORC_TREE)
+    feed = np.random.default_rng(4).integers(0, 1024, size=10)
+    for pos, tok in enumerate(feed):
+        a = Q.logits_array(mr, hip.forward(mr, int(tok), pos))
+        b = Q.logits_array(mo, orc.orc_forward(mo, int(tok), pos))
+        assert np.array_equal(a, b)
+    hip.q3_device_detach(mr)
+    ref.model_free(mr)
+    host.q3_model_close(mo)
