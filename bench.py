@@ -214,6 +214,8 @@ def main():
                    "parallelism": "1 GPU" if ngpu == 1 else f"pp{ngpu}: layer pipeline, RCCL send/recv of the residual, "
                                                             f"{ngpu} concurrent streams"},
     }
+    out["config"]["launch"] = ("persistent step kernel (1 launch/step)" if hip.q3_uses_persistent_kernel(m)
+                               else "hipGraph of per-stage kernels")
     bpt = hip.q3_bytes_per_token(C.byref(p), pos0 + W + K // 2)
     per_gpu_rate = out["value"] / ngpu
     out["hbm_roofline_frac_step"] = round(per_gpu_rate * bpt / 1e9 / HBM_PEAK_GBS * (1 if ngpu == 1 else 1.0), 4)

@@ -83,6 +83,9 @@ int q3_device_count(void);
 int q3_device_attach(Model* m);
 void q3_device_detach(Model* m);
 void q3_device_sync(Model* m);
+/* 1 when the steps of this Model run as the persistent single-launch kernel (q3_mega.hip):
+ * opt-in with Q3_MEGA=1, Qwen3-4B layer shapes on a 256-CU device. */
+int q3_uses_persistent_kernel(Model* m);
 
 /* One decode step without the logits copy: logits stay on the device.
  * Pair with q3_logits_fetch() or q3_device_argmax(). */

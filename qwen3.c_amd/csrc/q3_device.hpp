@@ -86,6 +86,18 @@ __device__ __forceinline__ float sum256_sq(const float* __restrict__ x, int n, i
     return bfly64((c0 + c1) + (c2 + c3));
 }
 
+// clamp(roundf(x / scale), +-127) as an int (reference src/q8.c:26-27) without paying for
+// an IEEE division per element: x * rcp(scale) is within ~2 ulp (< 4e-5 absolute, |q| <= 127)
+// of the correctly rounded quotient, so unless it lies within 1e-3 of a half-integer both
+// round to the same integer; only in that rare case is the true division carried out.
+// The result is the reference's in every case.
+__device__ __forceinline__ int q8_code(float x, float scale, float inv) {
+    float r = x * inv;
+    const float fr = fabsf(r - truncf(r));
+    if (fabsf(fr - 0.5f) < 1e-3f || !(fabsf(r) < 1.0e6f)) r = x / scale;
+    return (int)fminf(fmaxf(roundf(r), -127.0f), 127.0f);
+}
+
 // q8_quantize (reference src/q8.c:5-30) of one 64-wide group held by 16 consecutive
 // lanes, four consecutive values each.  Returns the 4 packed codes; `scale` gets the
 // group scale in every lane of the group.
@@ -96,10 +108,11 @@ __device__ __forceinline__ int quantize_group16(float4 y, float& scale) {
     amax = fmaxf(amax, lane_xor_f<4>(amax));
     amax = fmaxf(amax, lane_xor_f<8>(amax));
     scale = q3_q8_scale(amax);
-    const int q0 = (int)fminf(fmaxf(roundf(y.x / scale), -127.0f), 127.0f);
-    const int q1 = (int)fminf(fmaxf(roundf(y.y / scale), -127.0f), 127.0f);
-    const int q2 = (int)fminf(fmaxf(roundf(y.z / scale), -127.0f), 127.0f);
-    const int q3 = (int)fminf(fmaxf(roundf(y.w / scale), -127.0f), 127.0f);
+    const float inv = __builtin_amdgcn_rcpf(scale);
+    const int q0 = q8_code(y.x, scale, inv);
+    const int q1 = q8_code(y.y, scale, inv);
+    const int q2 = q8_code(y.z, scale, inv);
+    const int q3 = q8_code(y.w, scale, inv);
     return (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
 }
 

@@ -33,82 +33,28 @@
 
 #include "q3_device.hpp"
 #include "q3_kernels.hpp"
+#include "q3_tile.hpp"
 
 namespace q3k {
 
-template <int R, int NJ>
-struct Tile {
-    v4i w[R][NJ];
-    float s[R][NJ];
-};
-
-// Buffer descriptors of the weight codes and scales of one launch (wave-uniform, in
-// SGPRs): loads are `buffer_load ... soffset` with ONE per-lane offset VGPR, all row
-// arithmetic stays scalar, and rows >= d fall outside num_records and read as zero.
-struct WDesc {
-    __amdgpu_buffer_rsrc_t w, s;
-};
-__device__ __forceinline__ WDesc make_wdesc(const Gemv& a) {
-    WDesc d;
-    const size_t wbytes = (size_t)a.d * a.n;
-    d.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.W), 0, (int)wbytes, 0x00020000);
-    d.s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.S), 0, (int)(wbytes >> 4), 0x00020000);
-    return d;
+__device__ __forceinline__ WView make_wview(const Gemv& a) {
+    return make_wview(a.W, a.S, a.d, a.n);
 }
 
-// `task` must be wave-uniform (an SGPR value).
+// one task = R consecutive rows starting at task*R; `task` must be wave-uniform
 template <int R, int NJ>
-__device__ __forceinline__ void tile_load(Tile<R, NJ>& t, const Gemv& a, const WDesc& wd, int task, int lane) {
-    const int n = a.n, ngroups = a.n >> 6;
-    const int voff = lane * 16, vsoff = (lane >> 2) * 4;
-    const int tail = n - (NJ - 1) * 1024;        // bytes of the last wave-load of a row (<= 1024)
-    const int row0 = task * R;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int wbase = (row0 + r) * n;        // < 2^31 for every tensor of these models
-        const int sbase = (row0 + r) * ngroups * 4;
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            v4i w = {0, 0, 0, 0};
-            float s = 0.0f;
-            if (j < NJ - 1 || voff < tail) {
-                w = __builtin_amdgcn_raw_buffer_load_b128(wd.w, voff, wbase + j * 1024, 2 /* nt */);
-                s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wd.s, vsoff, sbase + j * 64, 2));
-            }
-            t.w[r][j] = w;
-            t.s[r][j] = s;
-        }
-    }
+__device__ __forceinline__ void tile_load(Tile<R, NJ>& t, const Gemv& a, const WView& wv, int task, int lane) {
+    (void)a;
+    tile_issue<R, NJ>(t, wv, task * R, lane);
 }
 
 template <int EPI, int R, int NJ>
 __device__ __forceinline__ void tile_compute(const Tile<R, NJ>& t, const Gemv& a, int task, int lane,
                                              const int8_t* lq, const float* ls) {
-    const int n = a.n, quad = lane >> 2;
     const int row0 = task * R;
     if (row0 >= a.d) return;
     float acc[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        const int off = j * 1024 + lane * 16;
-        const bool act = off < n;
-        v4i xv = {0, 0, 0, 0};
-        float sx = 0.0f;
-        if (act) {
-            xv = *reinterpret_cast<const v4i*>(lq + off);
-            sx = ls[j * 16 + quad];
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int dsum = quad_sum(dot16(t.w[r][j], xv));
-            const float p = ((float)dsum * t.s[r][j]) * sx;
-            acc[r] = act ? acc[r] + p : acc[r];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = bfly_quads(acc[r]);
+    tile_dot<R, NJ>(t, a.n, lane, lq, ls, acc);
     if (lane == 0) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -118,9 +64,7 @@ __device__ __forceinline__ void tile_compute(const Tile<R, NJ>& t, const Gemv& a
                 } else if (EPI == EPI_RESID) {
                     a.out[row0 + r] = a.out[row0 + r] + acc[r];
                 } else if ((r & 1) == 0) {
-                    const float g = acc[r], u = acc[(r + 1) % R];
-                    const float sig = 1.0f / (1.0f + q3_expf(-g));
-                    a.out[(row0 + r) >> 1] = (g * sig) * u;
+                    a.out[(row0 + r) >> 1] = swiglu_pair(acc[r], acc[(r + 1) % R]);
                 }
             }
         }
@@ -179,7 +123,7 @@ __global__ __launch_bounds__(MAXT) void k_gemv2(Gemv a, int ntasks, int tw) {
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     int task = (uwave < tw) ? (int)blockIdx.x * tw + uwave : ntasks;
     if (task > ntasks) task = ntasks;            // rows >= d read as zero through the descriptor
-    const WDesc wd = make_wdesc(a);
+    const WView wd = make_wview(a);
     Tile<R, NJ> A;
     tile_load<R, NJ>(A, a, wd, task, lane);
 

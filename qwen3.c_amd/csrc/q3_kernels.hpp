@@ -76,4 +76,38 @@ void swiglu(const float* g, const float* u, int n, float* out, hipStream_t st);
 void expf_map(const float* x, int n, float* out, hipStream_t st);
 void fill_random(float* p, size_t n, uint64_t seed, hipStream_t st);
 
+
+// ---- persistent step kernel (q3_mega.hip) --------------------------------------------
+struct MegaSync {                        // device memory, zeroed once at attach
+    unsigned long long shard[8][16];     // arrival counters, one 128-B line each
+    unsigned long long epoch;            // grid stages completed by all earlier launches
+    unsigned int error;                  // raised when a bounded spin gave up
+    unsigned int pad[13];
+};
+struct MegaLayer {
+    const int8_t *qkv_q, *wo_q, *gu_q, *dn_q;
+    const float *qkv_s, *wo_s, *gu_s, *dn_s;
+    const float *att_nw, *ffn_nw, *qnw, *knw;
+    float *kc, *vc;                      // this stream's K / V cache of the layer
+};
+struct Mega {
+    const Ctl* ctl;
+    MegaSync* sync;
+    const MegaLayer* layers;             // device array indexed by global layer id
+    int l0, l1;                          // layers [l0, l1) run in this launch
+    const int8_t* emb_q;                 // null: the residual is already in x (later pipeline stage)
+    const float* emb_s;
+    const int8_t* cls_q;                 // null: no classifier on this stage
+    const float* cls_s;
+    const float* out_nw;
+    const float* rope;                   // [seq][hd/2][2]
+    float *x, *qkv, *att_s, *h, *logits, *part;
+    int8_t* att_q;
+    int dim, hid, H, KV, hd, P, KVD, V, seq_pad, max_chunks;
+    unsigned long long* stamps;          // diagnostics (Q3_STAMPS=1): s_memrealtime marks of workgroup 0, layer l0+1
+};
+bool mega_supported(int dim, int hid, int H, int KV, int hd, int seq_pad);
+void step(const Mega* dev, const Mega& host, hipStream_t st);
+size_t step_lds_bytes(const Mega& m);
+
 }  // namespace q3k

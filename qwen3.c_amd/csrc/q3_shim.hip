@@ -106,6 +106,12 @@ struct Dev {
     size_t cache_floats = 0;      // floats of one stream's K (or V) cache of one layer
     std::vector<hipGraphExec_t> pgexec;   // [stream*2 + multi], step without the ctl upload
     int* ptokens = nullptr;       // last stage: [n_streams][cap] chosen tokens
+    // persistent step kernel (q3_mega.hip)
+    bool use_mega = false;
+    q3k::MegaSync* msync = nullptr;
+    std::vector<q3k::Mega> mega_host;      // per stream
+    std::vector<q3k::Mega*> mega_dev;
+    unsigned* merr_host = nullptr;         // pinned copy of MegaSync::error
     int ptokens_cap = 0;
     bool tap = false;
     std::vector<float> tap_host;
@@ -257,6 +263,58 @@ void pipeline_split(int L, int rank, int world, int* first, int* count) {
     q3_pipeline_layers(&p, rank, world, first, count);
 }
 
+// The persistent step kernel: one launch per step instead of ~180 (q3_mega.hip).  Opt-in
+// (Q3_MEGA=1) while it is slower than the graph of per-stage kernels;
+// needs a shape it is compiled for and the 256 CUs it sizes itself to.
+void setup_mega(Dev* d) {
+    const char* e = getenv("Q3_MEGA");
+    if (!(e && e[0] == '1')) return;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, d->device));
+    if (prop.multiProcessorCount != 256) return;
+    if (!q3k::mega_supported(d->dim, d->hid, d->H, d->KV, d->hd, d->seq_pad)) return;
+    d->msync = dalloc<q3k::MegaSync>(d, 1);
+    HIPCHK(hipMemsetAsync(d->msync, 0, sizeof(q3k::MegaSync), d->st));
+    HIPCHK(hipHostMalloc((void**)&d->merr_host, sizeof(unsigned), hipHostMallocDefault));
+    *d->merr_host = 0;
+    d->mega_host.resize(d->n_streams);
+    d->mega_dev.resize(d->n_streams);
+    for (int s = 0; s < d->n_streams; s++) {
+        std::vector<q3k::MegaLayer> tab(d->L);
+        memset(tab.data(), 0, tab.size() * sizeof(q3k::MegaLayer));
+        for (int l = d->l0; l < d->l1; l++) {
+            const LayerDev& L = d->layers[l];
+            q3k::MegaLayer& t = tab[l];
+            t.qkv_q = L.qkv_q; t.wo_q = L.wo_q; t.gu_q = L.gu_q; t.dn_q = L.dn_q;
+            t.qkv_s = L.qkv_s; t.wo_s = L.wo_s; t.gu_s = L.gu_s; t.dn_s = L.dn_s;
+            t.att_nw = L.att_nw; t.ffn_nw = L.ffn_nw; t.qnw = L.qnw; t.knw = L.knw;
+            t.kc = L.kc + (size_t)s * d->cache_floats;
+            t.vc = L.vc + (size_t)s * d->cache_floats;
+        }
+        q3k::MegaLayer* dtab = upload<q3k::MegaLayer>(d, tab.data(), tab.size());
+        q3k::Mega& m = d->mega_host[s];
+        memset(&m, 0, sizeof(m));
+        m.ctl = d->ctl; m.sync = d->msync; m.layers = dtab; m.l0 = d->l0; m.l1 = d->l1;
+        m.emb_q = d->has_embed ? d->emb_q : nullptr; m.emb_s = d->emb_s;
+        m.cls_q = d->has_cls ? d->cls_q : nullptr; m.cls_s = d->cls_s; m.out_nw = d->out_nw;
+        m.rope = d->rope;
+        m.x = d->x; m.qkv = d->qkv; m.att_s = d->att_s; m.h = d->h; m.logits = d->logits; m.part = d->part;
+        m.att_q = d->att_q;
+        m.dim = d->dim; m.hid = d->hid; m.H = d->H; m.KV = d->KV; m.hd = d->hd; m.P = d->P; m.KVD = d->KVD;
+        m.V = d->V; m.seq_pad = d->seq_pad; m.max_chunks = d->max_chunks;
+        m.stamps = d->stamps;
+        if (q3k::step_lds_bytes(m) > 160 * 1024) return;      // this stage's layer table does not fit
+        d->mega_dev[s] = upload<q3k::Mega>(d, &m, 1);
+    }
+    d->use_mega = true;
+}
+
+void check_mega_error(Dev* d) {
+    if (d->use_mega && d->merr_host && *d->merr_host) {
+        Q3_DIE("the persistent step kernel gave up waiting on a hand-off (MegaSync::error = %u)", *d->merr_host);
+    }
+}
+
 Dev* attach(Model* m) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -325,6 +383,7 @@ Dev* attach(Model* m) {
         if (!d->logits_pinned) (void)hipGetLastError();
     }
     d->tap_host.assign((size_t)d->L * d->dim, 0.0f);
+    setup_mega(d);
     HIPCHK(hipStreamSynchronize(d->st));
 
     std::lock_guard<std::mutex> lk(g_mu);
@@ -457,6 +516,11 @@ void enqueue_head(Dev* d) {
 
 // everything of one step that runs on this device, between the ctl upload and the logits
 void enqueue_step(Dev* d, bool multi, int stream = 0) {
+    if (d->use_mega && !d->prof && !d->tap) {
+        q3k::step(d->mega_dev[stream], d->mega_host[stream], d->st);
+        HIPCHK(hipMemcpyAsync(d->merr_host, &d->msync->error, sizeof(unsigned), hipMemcpyDeviceToHost, d->st));
+        return;
+    }
     {
         Timed t(d, "begin", 0.0);
         q3k::begin_step(d->ctl, d->has_embed ? d->emb_q : nullptr, d->emb_s, d->dim, d->x, d->rope, d->hd,
@@ -501,7 +565,10 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
         hipGraphExec_t& ex = d->gexec[multi ? 1 : 0];
         if (!ex) ex = build_graph(d, multi, true);
         HIPCHK(hipGraphLaunch(ex, d->st));
-        if (to_host) HIPCHK(hipStreamSynchronize(d->st));
+        if (to_host) {
+            HIPCHK(hipStreamSynchronize(d->st));
+            check_mega_error(d);
+        }
         return;
     }
     HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
@@ -620,13 +687,23 @@ void q3_device_detach(Model* m) {
     for (void* p : d->allocs) (void)hipFree(p);
     (void)hipHostFree(d->ctl_host);
     (void)hipHostFree(d->amax_host);
+    if (d->merr_host) (void)hipHostFree(d->merr_host);
     (void)hipStreamDestroy(d->st);
     delete d;
 }
 
+/* 1 when steps of this Model run as the persistent single-launch kernel */
+int q3_uses_persistent_kernel(Model* m) {
+    Dev* d = attach(m);
+    return d->use_mega ? 1 : 0;
+}
+
 void q3_device_sync(Model* m) {
     Dev* d = lookup(m);
-    if (d) HIPCHK(hipStreamSynchronize(d->st));
+    if (d) {
+        HIPCHK(hipStreamSynchronize(d->st));
+        check_mega_error(d);
+    }
 }
 
 float* forward(Model* m, int token, int pos) {

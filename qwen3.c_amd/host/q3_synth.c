@@ -126,6 +126,9 @@ int q3_synth_preset(const char* name, Q3SynthSpec* s) {
     } else if (!strcmp(name, "small")) {  /* GQA 4:1, head_dim 128, ragged group counts */
         s->dim = 320; s->hidden_dim = 704; s->n_layers = 3; s->n_heads = 4; s->n_kv_heads = 1;
         s->head_dim = 128; s->vocab_size = 1024; s->seq_len = 512; s->shared_classifier = 0;
+    } else if (!strcmp(name, "4Bmini")) { /* Qwen3-4B layer shapes, 2 layers, small vocabulary */
+        s->dim = 2560; s->hidden_dim = 9728; s->n_layers = 2; s->n_heads = 32;
+        s->vocab_size = 8192; s->seq_len = 1024;
     } else if (!strcmp(name, "0.6B")) {
         s->dim = 1024; s->hidden_dim = 3072; s->n_layers = 28; s->n_heads = 16;
     } else if (!strcmp(name, "1.7B")) {

@@ -5,7 +5,7 @@ if len(sys.argv) > 2: os.environ["HIP_FORCE_DEV_KERNARG"] = sys.argv[2]
 os.environ["Q3_GRAPH"] = sys.argv[1] if len(sys.argv) > 1 else "1"
 import numpy as np, q3lib as Q
 hip = Q.hip_lib()
-path = "/tmp/q3/4B.bin"; Q.synth("4B", path)
+os.makedirs("/tmp/q3", exist_ok=True); path = "/tmp/q3/4B.bin"; Q.synth("4B", path)
 m = hip.q3_model_open(path.encode(), 1024, 0)
 hip.q3_debug_stamps.argtypes = [Q.ModelP, C.POINTER(C.c_uint64), C.c_int]
 tok = 9707
