@@ -53,8 +53,12 @@ __global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
     // ---- everything that can be requested before any arithmetic ------------------
     const int pos = a.ctl->pos;
     float4 kt[NLD], vt[NLD];
+    // Slot 0 always has work (chunk 0), so it requests its tile before `pos` has even arrived;
+    // the other slots first learn whether their chunk exists -- a speculative 64 KB per idle
+    // workgroup would cost tens of MB of useless HBM reads per layer at short contexts.
+    if (blockIdx.y != 0 && (int)blockIdx.y * CH > pos) return;
     {
-        const int t0 = (int)blockIdx.y * CH;    // speculative: rows beyond pos are never used
+        const int t0 = (int)blockIdx.y * CH;    // rows beyond pos are loaded but never used
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
             const int idx = tid + k * 256;
@@ -233,29 +237,60 @@ __global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
     STAMP(7);
 }
 
-// merge of the chunk partials (q3_numerics.h "attention", last three lines) + quantise
+// merge of the chunk partials (q3_numerics.h "attention", last three lines) + quantise.
+// One wave per head.  The sums over chunks are sequential by contract, but nothing forces the
+// LOADS to be: the (m_c, l_c) pairs are fetched 64 chunks at a time (one per lane) and the
+// O_c rows eight chunks ahead of the accumulation.
 template <int HD>
 __global__ __launch_bounds__(64) void k_attn_combine(Attn a) {
     constexpr int L4 = HD / 4;
+    constexpr int ST = HD + 2;
     const int h = blockIdx.x, lane = threadIdx.x;
     const int T = a.ctl->pos + 1;
     const int nchunks = (T + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
-    const float* base = a.part + (size_t)h * a.max_chunks * (HD + 2);
-    float M = base[HD];
-    for (int c = 1; c < nchunks; c++) M = fmaxf(M, base[(size_t)c * (HD + 2) + HD]);
+    const float* base = a.part + (size_t)h * a.max_chunks * ST;
+    // pass 1: the running maximum of m_c
+    float M = -3.0e38f;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        const int c = c0 + lane;
+        const float mc = c < nchunks ? base[(size_t)c * ST + HD] : -3.0e38f;
+        M = fmaxf(M, wave_max(mc));
+    }
+    // pass 2: L and A, ascending c
     float L = 0.0f;
     float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < nchunks; c++) {
-        const float* pp = base + (size_t)c * (HD + 2);
-        const float w = q3_expf(pp[HD] - M);
-        L = L + w * pp[HD + 1];
-        if (lane < L4) {
-            const float2 o01 = *reinterpret_cast<const float2*>(pp + 4 * lane);
-            const float2 o23 = *reinterpret_cast<const float2*>(pp + 4 * lane + 2);
-            A.x = A.x + w * o01.x;
-            A.y = A.y + w * o01.y;
-            A.z = A.z + w * o23.x;
-            A.w = A.w + w * o23.y;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        const int c = c0 + lane;
+        float wc = 0.0f, wl = 0.0f;
+        if (c < nchunks) {
+            wc = q3_expf(base[(size_t)c * ST + HD] - M);
+            wl = wc * base[(size_t)c * ST + HD + 1];
+        }
+        const int cnt = (nchunks - c0 < 64) ? nchunks - c0 : 64;
+        for (int k0 = 0; k0 < cnt; k0 += 8) {
+            float4 o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + k < cnt && lane < L4) {
+                    const float* pp = base + (size_t)(c0 + k0 + k) * ST + 4 * lane;
+                    const float2 lo = *reinterpret_cast<const float2*>(pp);
+                    const float2 hi = *reinterpret_cast<const float2*>(pp + 2);
+                    o[k] = make_float4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k0 + k < cnt) {
+                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wc), (k0 + k) & 63));
+                    const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), (k0 + k) & 63));
+                    L = L + t;
+                    A.x = A.x + w * o[k].x;
+                    A.y = A.y + w * o[k].y;
+                    A.z = A.z + w * o[k].z;
+                    A.w = A.w + w * o[k].w;
+                }
+            }
         }
     }
     float4 y = make_float4(0.f, 0.f, 0.f, 0.f);

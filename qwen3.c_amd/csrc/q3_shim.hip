@@ -365,7 +365,7 @@ Dev* attach(Model* m) {
     d->att_f = dalloc<float>(d, d->P);
     d->cs_cur = dalloc<float>(d, d->hd);
     d->max_chunks = (d->seq + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
-    d->chunk_slots = d->max_chunks < 64 ? d->max_chunks : 64;
+    d->chunk_slots = d->max_chunks < 256 ? d->max_chunks : 256;   // one workgroup per (kv head, chunk) up to 16k positions
     d->part = dalloc<float>(d, (size_t)d->H * d->max_chunks * (d->hd + 2));
     d->tap_dev = dalloc<float>(d, (size_t)d->L * d->dim);
     d->ctl = dalloc<q3k::Ctl>(d, 1);
@@ -477,9 +477,14 @@ void enqueue_layer(Dev* d, int l, bool multi, int stream = 0) {
     }
     {   // head norms + RoPE + cache append + attention + quantise (forward.c:267-291)
         q3k::Attn a = attn_args(d, l, stream);
-        Timed t(d, "attn", 0.0);
-        q3k::attn(a, multi ? d->chunk_slots : 1, multi, d->st);
-        if (multi) q3k::attn_combine(a, d->st);
+        {
+            Timed t(d, "attn", 0.0);
+            q3k::attn(a, multi ? d->chunk_slots : 1, multi, d->st);
+        }
+        if (multi) {
+            Timed t(d, "attn_combine", 0.0);
+            q3k::attn_combine(a, d->st);
+        }
     }
     {   // Wo + residual (forward.c:292-298)
         g.W = L.wo_q; g.S = L.wo_s; g.n = d->P; g.d = d->dim;

@@ -6,12 +6,14 @@ os.environ["Q3_GRAPH"] = sys.argv[1] if len(sys.argv) > 1 else "1"
 import numpy as np, q3lib as Q
 hip = Q.hip_lib()
 os.makedirs("/tmp/q3", exist_ok=True); path = "/tmp/q3/4B.bin"; Q.synth("4B", path)
-m = hip.q3_model_open(path.encode(), 1024, 0)
+CTX = int(os.environ.get('CTX', '0'))
+m = hip.q3_model_open(path.encode(), max(1024, CTX + 128), 0)
+if CTX: hip.q3_kv_fill_random(m, CTX, 5)
 hip.q3_debug_stamps.argtypes = [Q.ModelP, C.POINTER(C.c_uint64), C.c_int]
 tok = 9707
-for pos in range(40):
+for pos in range(CTX, CTX + 40):
     lg = hip.forward(m, tok, pos); tok = hip.q3_argmax(lg, 151936)
-    if pos in (0, 1, 5, 20, 39):
+    if pos - CTX in (0, 1, 5, 20, 39):
         buf = (C.c_uint64 * 16)(); hip.q3_debug_stamps(m, buf, 16)
         rt = [buf[2*i] for i in range(8)]; cy = [buf[2*i+1] for i in range(8)]
         d_rt = [(rt[i]-rt[0])*10 for i in range(8)]   # ns
