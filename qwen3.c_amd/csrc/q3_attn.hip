@@ -15,7 +15,8 @@
 // position, raw q/k/v, norm weights, the (cos,sin) row of this position and,
 // speculatively, the whole first K/V tile -- so the step costs one memory round trip.
 //
-// Chunk partials (m_c, l_c, O_c) are merged by k_attn_combine when pos >= 64; below
+// When pos >= 64 every workgroup publishes its chunk partials (m_c, l_c, O_c) and the one that
+// draws the last ticket of its kv head merges them inside the same launch; below
 // that the kernel normalises and quantises directly.
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,89 @@ namespace q3k {
 #define STAMP(i) do {} while (0)
 #endif
 
+typedef __attribute__((address_space(1))) unsigned g_u32;
+
+// write-through 8-byte store / cache-bypassing loads for data handed to another workgroup
+// inside the launch
+__device__ __forceinline__ void st_sc1_f2(float* p, float x, float y) {
+    const unsigned long long v = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
+    __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)p, v, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_sc1_f2(const float* p) {
+    const unsigned long long v = __hip_atomic_load((__attribute__((address_space(1))) unsigned long long*)p,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+
+// Merge of the chunk partials of one head (q3_numerics.h "attention", last three lines) +
+// q8_quantize, by ONE wave.  The sums over chunks are sequential by contract, but nothing
+// forces the LOADS to be: the (m_c, l_c) pairs are fetched 64 chunks at a time (one per lane)
+// and the O_c rows eight chunks ahead of the accumulation.
+template <int HD>
+__device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks, int lane) {
+    constexpr int L4 = HD / 4;
+    constexpr int ST = HD + 2;
+    const float* base = a.part + (size_t)h * a.max_chunks * ST;
+    float M = -3.0e38f;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        const int c = c0 + lane;
+        const float mc = c < nchunks ? ld_sc1_f2(base + (size_t)c * ST + HD).x : -3.0e38f;
+        M = fmaxf(M, wave_max(mc));
+    }
+    float L = 0.0f;
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        const int c = c0 + lane;
+        float wc = 0.0f, wl = 0.0f;
+        if (c < nchunks) {
+            const float2 ml = ld_sc1_f2(base + (size_t)c * ST + HD);
+            wc = q3_expf(ml.x - M);
+            wl = wc * ml.y;
+        }
+        const int cnt = (nchunks - c0 < 64) ? nchunks - c0 : 64;
+        for (int k0 = 0; k0 < cnt; k0 += 8) {
+            float4 o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + k < cnt && lane < L4) {
+                    const float* pp = base + (size_t)(c0 + k0 + k) * ST + 4 * lane;
+                    const float2 lo = ld_sc1_f2(pp);
+                    const float2 hi = ld_sc1_f2(pp + 2);
+                    o[k] = make_float4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k0 + k < cnt) {
+                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wc), (k0 + k) & 63));
+                    const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), (k0 + k) & 63));
+                    L = L + t;
+                    A.x = A.x + w * o[k].x;
+                    A.y = A.y + w * o[k].y;
+                    A.z = A.z + w * o[k].z;
+                    A.w = A.w + w * o[k].w;
+                }
+            }
+        }
+    }
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < L4) {
+        y.x = A.x / L;
+        y.y = A.y / L;
+        y.z = A.z / L;
+        y.w = A.w / L;
+    }
+    float scale;
+    const int packed = quantize_group16(y, scale);
+    if (lane < L4) {
+        reinterpret_cast<int*>(a.oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
+        if ((lane & 15) == 0) a.os[((size_t)h * HD + 4 * lane) >> 6] = scale;
+        if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
+    }
+}
+
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
     constexpr int L4 = HD / 4;               // lanes holding one head as float4
@@ -40,6 +124,7 @@ __global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
     constexpr int NLD = CH * L4 / 256;       // float4 loads per thread per tile
     __shared__ __attribute__((aligned(16))) float Ks[CH * HD];
     __shared__ __attribute__((aligned(16))) float Vs[CH * HD];
+    __shared__ int last_flag;
 
     const int g = blockIdx.x;
     const int kv_mul = a.n_heads / a.n_kv;
@@ -207,13 +292,11 @@ __global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
             o.w = acc.w + lane_xor_f<32>(acc.w);
             if (multi) {
                 if (lane < L4) {
+                    // write-through (sc1) stores: another workgroup of this launch reads them
                     float* pp = a.part + ((size_t)h * a.max_chunks + c) * (HD + 2);
-                    *reinterpret_cast<float2*>(pp + 4 * lane) = make_float2(o.x, o.y);
-                    *reinterpret_cast<float2*>(pp + 4 * lane + 2) = make_float2(o.z, o.w);
-                    if (lane == 0) {
-                        pp[HD] = m;
-                        pp[HD + 1] = lsum;
-                    }
+                    st_sc1_f2(pp + 4 * lane, o.x, o.y);
+                    st_sc1_f2(pp + 4 * lane + 2, o.z, o.w);
+                    if (lane == 0) st_sc1_f2(pp + HD, m, lsum);
                 }
             } else {
                 // q8_quantize of the head output (forward.c:291): 64-wide groups of 16 lanes
@@ -233,80 +316,24 @@ __global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
                 }
             }
         }
+        if (multi) {
+            // Publish: every storing wave drains its write-through stores, the workgroup meets,
+            // ONE lane takes a ticket (Guideline 16, counter form).  The workgroup whose ticket
+            // is the last of its kv head merges the partials of the head's chunks right here.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned t = __hip_atomic_fetch_add((g_u32*)(a.tickets + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last_flag = (t == (unsigned)(nchunks - 1)) ? 1 : 0;
+                if (last_flag) __hip_atomic_store((g_u32*)(a.tickets + g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (last_flag) {
+                for (int i = wave; i < kv_mul; i += 4) merge_partials<HD>(a, g * kv_mul + i, nchunks, lane);
+            }
+        }
     }
     STAMP(7);
-}
-
-// merge of the chunk partials (q3_numerics.h "attention", last three lines) + quantise.
-// One wave per head.  The sums over chunks are sequential by contract, but nothing forces the
-// LOADS to be: the (m_c, l_c) pairs are fetched 64 chunks at a time (one per lane) and the
-// O_c rows eight chunks ahead of the accumulation.
-template <int HD>
-__global__ __launch_bounds__(64) void k_attn_combine(Attn a) {
-    constexpr int L4 = HD / 4;
-    constexpr int ST = HD + 2;
-    const int h = blockIdx.x, lane = threadIdx.x;
-    const int T = a.ctl->pos + 1;
-    const int nchunks = (T + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
-    const float* base = a.part + (size_t)h * a.max_chunks * ST;
-    // pass 1: the running maximum of m_c
-    float M = -3.0e38f;
-    for (int c0 = 0; c0 < nchunks; c0 += 64) {
-        const int c = c0 + lane;
-        const float mc = c < nchunks ? base[(size_t)c * ST + HD] : -3.0e38f;
-        M = fmaxf(M, wave_max(mc));
-    }
-    // pass 2: L and A, ascending c
-    float L = 0.0f;
-    float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c0 = 0; c0 < nchunks; c0 += 64) {
-        const int c = c0 + lane;
-        float wc = 0.0f, wl = 0.0f;
-        if (c < nchunks) {
-            wc = q3_expf(base[(size_t)c * ST + HD] - M);
-            wl = wc * base[(size_t)c * ST + HD + 1];
-        }
-        const int cnt = (nchunks - c0 < 64) ? nchunks - c0 : 64;
-        for (int k0 = 0; k0 < cnt; k0 += 8) {
-            float4 o[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k0 + k < cnt && lane < L4) {
-                    const float* pp = base + (size_t)(c0 + k0 + k) * ST + 4 * lane;
-                    const float2 lo = *reinterpret_cast<const float2*>(pp);
-                    const float2 hi = *reinterpret_cast<const float2*>(pp + 2);
-                    o[k] = make_float4(lo.x, lo.y, hi.x, hi.y);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (k0 + k < cnt) {
-                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wc), (k0 + k) & 63));
-                    const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), (k0 + k) & 63));
-                    L = L + t;
-                    A.x = A.x + w * o[k].x;
-                    A.y = A.y + w * o[k].y;
-                    A.z = A.z + w * o[k].z;
-                    A.w = A.w + w * o[k].w;
-                }
-            }
-        }
-    }
-    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < L4) {
-        y.x = A.x / L;
-        y.y = A.y / L;
-        y.z = A.z / L;
-        y.w = A.w / L;
-    }
-    float scale;
-    const int packed = quantize_group16(y, scale);
-    if (lane < L4) {
-        reinterpret_cast<int*>(a.oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
-        if ((lane & 15) == 0) a.os[((size_t)h * HD + 4 * lane) >> 6] = scale;
-        if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
-    }
 }
 
 void attn(const Attn& a, int chunk_slots, bool multi, hipStream_t st) {
@@ -321,11 +348,6 @@ void attn(const Attn& a, int chunk_slots, bool multi, hipStream_t st) {
         fprintf(stderr, "[q3hip] attention: head_dim %d not supported (64 or 128)\n", a.hd);
         exit(EXIT_FAILURE);
     }
-}
-
-void attn_combine(const Attn& a, hipStream_t st) {
-    if (a.hd == 128) hipLaunchKernelGGL(k_attn_combine<128>, dim3(a.n_heads), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(k_attn_combine<64>, dim3(a.n_heads), dim3(64), 0, st, a);
 }
 
 // start of a step on one device: embedding row (when this stage owns it) and the

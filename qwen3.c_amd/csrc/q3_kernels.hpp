@@ -41,6 +41,7 @@ struct Attn {
     float* kc;           // this layer's K cache [n_kv][seq_len][hd], seq_len a multiple of 64
     float* vc;           // this layer's V cache, same layout
     float* part;         // chunk partials [n_heads][max_chunks][hd+2]
+    unsigned* tickets;   // [n_kv] arrival tickets of the chunk workgroups (zero between launches)
     int8_t* oq;          // attention output codes [P]
     float* os;           // attention output scales [P/64]
     float* of;           // optional fp32 copy of the head outputs [P] (may be null)
@@ -49,11 +50,11 @@ struct Attn {
     unsigned long long* stamps;  // diagnostic builds only: s_memrealtime/s_memtime marks of workgroup (0,0)
     int prepared;        // op-level test hook only: q and the k/v of `pos` are already normed + rotated
 };
-// `chunk_slots` workgroups per kv head walk the 64-position chunks of [0,pos];
-// with multi=false the caller guarantees pos < 64 and the kernel finalises itself,
-// otherwise attn_combine() must follow.
+// `chunk_slots` workgroups per kv head walk the 64-position chunks of [0,pos].  With
+// multi=false the caller guarantees pos < 64 (one chunk, finalised directly); otherwise each
+// workgroup publishes its chunk partials and the one that draws the last ticket of its kv head
+// merges them -- inside the same launch.
 void attn(const Attn& a, int chunk_slots, bool multi, hipStream_t st);
-void attn_combine(const Attn& a, hipStream_t st);
 
 void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, hipStream_t st);
 // first kernel of a step: x = embedding row of ctl->token (eq may be null on later pipeline

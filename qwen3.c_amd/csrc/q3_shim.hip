@@ -95,6 +95,7 @@ struct Dev {
     q3k::Ctl* ctl = nullptr;
     q3k::Ctl* ctl_host = nullptr;
     int* amax = nullptr;
+    unsigned* tickets = nullptr;  // attention chunk tickets, [KV], zero between launches
     unsigned long long* stamps = nullptr;
     int* amax_host = nullptr;
     int max_chunks = 1, chunk_slots = 1;
@@ -370,6 +371,8 @@ Dev* attach(Model* m) {
     d->tap_dev = dalloc<float>(d, (size_t)d->L * d->dim);
     d->ctl = dalloc<q3k::Ctl>(d, 1);
     d->amax = dalloc<int>(d, 1);
+    d->tickets = dalloc<unsigned>(d, d->KV);
+    HIPCHK(hipMemsetAsync(d->tickets, 0, (size_t)d->KV * sizeof(unsigned), d->st));
     if (d->loopback) {
         for (int i = 0; i < 2; i++) d->outbox[i] = dalloc<float>(d, d->dim + 1);
     }
@@ -459,7 +462,8 @@ q3k::Attn attn_args(Dev* d, int l, int stream = 0) {
     const LayerDev& L = d->layers[l];
     q3k::Attn a;
     a.ctl = d->ctl; a.qkv = d->qkv; a.qnw = L.qnw; a.knw = L.knw; a.cs = d->cs_cur;
-    a.kc = L.kc + (size_t)stream * d->cache_floats; a.vc = L.vc + (size_t)stream * d->cache_floats; a.part = d->part; a.oq = d->att_q; a.os = d->att_s;
+    a.kc = L.kc + (size_t)stream * d->cache_floats; a.vc = L.vc + (size_t)stream * d->cache_floats; a.part = d->part;
+    a.tickets = d->tickets; a.oq = d->att_q; a.os = d->att_s;
     a.of = nullptr; a.qdbg = nullptr; a.prepared = 0; a.stamps = d->stamps;
     a.n_heads = d->H; a.n_kv = d->KV; a.hd = d->hd; a.seq_len = d->seq_pad; a.max_chunks = d->max_chunks;
     return a;
@@ -480,10 +484,6 @@ void enqueue_layer(Dev* d, int l, bool multi, int stream = 0) {
         {
             Timed t(d, "attn", 0.0);
             q3k::attn(a, multi ? d->chunk_slots : 1, multi, d->st);
-        }
-        if (multi) {
-            Timed t(d, "attn_combine", 0.0);
-            q3k::attn_combine(a, d->st);
         }
     }
     {   // Wo + residual (forward.c:292-298)
@@ -996,7 +996,6 @@ void attention(Model* m, int layer, int pos) {
     a.of = d->att_f;
     const bool multi = pos >= Q3_ATT_CHUNK;
     q3k::attn(a, multi ? d->chunk_slots : 1, multi, d->st);
-    if (multi) q3k::attn_combine(a, d->st);
     HIPCHK(hipStreamSynchronize(d->st));
     if (m->state.x_rms_norm) {
         HIPCHK(hipMemcpy(m->state.x_rms_norm, d->att_f, (size_t)d->P * 4, hipMemcpyDeviceToHost));
@@ -1080,19 +1079,20 @@ void q3_op_attention(const float* q, const float* kcache, const float* vcache, i
     const int max_chunks = (T + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
     DBuf dqkv(qkv.data(), qkv.size() * 4), dkc(kc.data(), kc.size() * 4), dvc(vc.data(), vc.size() * 4);
     DBuf dpart((size_t)n_heads * max_chunks * (hd + 2) * 4), doq((size_t)P), dos((size_t)P / 64 * 4 + 16);
+    DBuf dtick((size_t)n_kv_heads * 4);
+    HIPCHK(hipMemset(dtick.p, 0, dtick.bytes));
     DBuf dof((size_t)P * 4);
     q3k::Ctl ctl = {0, T - 1};
     DBuf dctl(&ctl, sizeof(ctl));
     q3k::Attn a;
     memset(&a, 0, sizeof(a));
     a.ctl = dctl.as<q3k::Ctl>(); a.qkv = dqkv.as<float>(); a.qnw = nullptr; a.knw = nullptr; a.cs = nullptr;
-    a.kc = dkc.as<float>(); a.vc = dvc.as<float>(); a.part = dpart.as<float>();
+    a.kc = dkc.as<float>(); a.vc = dvc.as<float>(); a.part = dpart.as<float>(); a.tickets = dtick.as<unsigned>();
     a.oq = doq.as<int8_t>(); a.os = dos.as<float>(); a.of = dof.as<float>(); a.qdbg = nullptr;
     a.n_heads = n_heads; a.n_kv = n_kv_heads; a.hd = hd; a.seq_len = seq; a.max_chunks = max_chunks;
     a.prepared = 1;
     const bool multi = T > Q3_ATT_CHUNK;
-    q3k::attn(a, multi ? (max_chunks < 64 ? max_chunks : 64) : 1, multi, st);
-    if (multi) q3k::attn_combine(a, st);
+    q3k::attn(a, multi ? max_chunks : 1, multi, st);
     dof.to_host(out, st);
 }
 
