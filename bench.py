@@ -245,14 +245,33 @@ def main():
                 us = 1000.0 * e.ms_total / e.launches
                 kern[e.name.decode()] = {"launches": int(e.launches), "us": round(us, 3),
                                          "GBps": round(e.bytes_per_launch / us / 1e3, 1) if e.bytes_per_launch else None}
+        for name in kern:      # the same launches by the device clock read inside the kernel
+            dus = hip.q3_prof_device_us(m, name.encode())
+            if dus > 0:
+                kern[name]["us_device_clock"] = round(dus, 3)
         dom = kern.get("gateup")
         if dom:
-            ach = dom["GBps"]
-            out["roofline"] = {"bound": "hbm", "kernel": "k_gemv<PRO_NORM,EPI_SWIGLU> (gate/up GEMV)",
+            # duration of a launch = first workgroup in .. last workgroup out by s_memrealtime inside
+            # the kernel when available (agrees with rocprofv3's dispatch durations); the HIP-event
+            # bracket of the same launches is reported next to it
+            us_best = dom.get("us_device_clock") or dom["us"]
+            ach = round(hip.q3_gemv_bytes(2 * p.hidden_dim, p.dim) / us_best / 1e3, 1)
+            traffic = None
+            try:   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["gateup"]
+                if args.model == "4B":
+                    traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
+            except Exception:
+                pass
+            out["roofline"] = {"bound": "hbm", "kernel": "k_gemv2<PRO_NORM,EPI_SWIGLU> (gate/up GEMV)",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "timing": "in-kernel device clock (s_memrealtime, first workgroup in .. last out) of the "
+                                         "same launches that the HIP events bracket on the launch stream; "
+                                         "us_per_launch_events includes the end-of-kernel release (~2 us)",
+                               "us_per_launch_events": dom["us"],
                                "bytes_per_launch": int(hip.q3_gemv_bytes(2 * p.hidden_dim, p.dim)),
-                               "us_per_launch": dom["us"]}
+                               "us_per_launch": us_best}
         out["kernels"] = kern
     hip.q3_model_close(m)
 

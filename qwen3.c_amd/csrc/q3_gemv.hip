@@ -78,6 +78,7 @@ __global__ __launch_bounds__(MAXT) void k_gemv2(Gemv a, int ntasks, int tw) {
     const int n = a.n;
     const int NT = blockDim.x, NW = NT >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.clk && tid == 0) atomicMin(a.clk, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     float* lx = reinterpret_cast<float*>(smem);
     int8_t* lq = reinterpret_cast<int8_t*>(smem + (PRO == PRO_NORM ? (size_t)n * 4 : 0));
     float* ls = reinterpret_cast<float*>(lq + n);
@@ -202,6 +203,11 @@ __global__ __launch_bounds__(MAXT) void k_gemv2(Gemv a, int ntasks, int tw) {
             tile_compute<EPI, R, NJ>(B, a, task, lane, lq, ls);
             task = nxt;
         }
+    }
+    if (a.clk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) atomicMax(a.clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 

@@ -211,28 +211,28 @@ void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x,
     hipLaunchKernelGGL(k_embed, dim3((dim + 255) / 256), dim3(256), 0, st, ctl, eq, es, dim, x);
 }
 
-// first index of the maximum (what a strict `>` scan returns), one workgroup
-__global__ __launch_bounds__(1024) void k_argmax(const float* __restrict__ logits, int n, int* out,
-                                                 int* out2) {
-    __shared__ float bv[16];
-    __shared__ int bi[16];
+// first index of the maximum (what a strict `>` scan returns), in two small launches:
+// 128 workgroups reduce slices to (value, index) pairs, one wave picks among those
+__device__ __forceinline__ void argmax_merge(float& v, int& idx, float ov, int oi) {
+    if (ov > v || (ov == v && oi < idx)) {
+        v = ov;
+        idx = oi;
+    }
+}
+#define Q3_ARGMAX_WGS 128
+__global__ __launch_bounds__(256) void k_argmax_part(const float* __restrict__ logits, int n, float* pv, int* pi) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
     float v = -3.4e38f;
     int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += Q3_ARGMAX_WGS * 256) {
         const float x = logits[i];
-        if (x > v) {
+        if (x > v) {        // ascending i per thread: strict > keeps the first
             v = x;
             idx = i;
         }
     }
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = __shfl_xor(v, m, 64);
-        const int oi = __shfl_xor(idx, m, 64);
-        if (ov > v || (ov == v && oi < idx)) {
-            v = ov;
-            idx = oi;
-        }
-    }
+    for (int m = 32; m >= 1; m >>= 1) argmax_merge(v, idx, __shfl_xor(v, m, 64), __shfl_xor(idx, m, 64));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) {
         bv[wave] = v;
@@ -240,18 +240,27 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* __restrict__ logit
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; w++) {
-            if (bv[w] > v || (bv[w] == v && bi[w] < idx)) {
-                v = bv[w];
-                idx = bi[w];
-            }
-        }
+        for (int w = 1; w < 4; w++) argmax_merge(v, idx, bv[w], bi[w]);
+        pv[blockIdx.x] = v;
+        pi[blockIdx.x] = idx;
+    }
+}
+__global__ __launch_bounds__(64) void k_argmax_final(const float* pv, const int* pi, int* out, int* out2) {
+    const int lane = threadIdx.x;
+    float v = pv[lane];
+    int idx = pi[lane];
+    argmax_merge(v, idx, pv[lane + 64], pi[lane + 64]);
+    for (int m = 32; m >= 1; m >>= 1) argmax_merge(v, idx, __shfl_xor(v, m, 64), __shfl_xor(idx, m, 64));
+    if (lane == 0) {
         *out = idx;
         if (out2) *out2 = idx;
     }
 }
-void argmax(const float* logits, int n, int* out, int* out2, hipStream_t st) {
-    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, st, logits, n, out, out2);
+void argmax(const float* logits, int n, float* scratch /* 2*128 words */, int* out, int* out2, hipStream_t st) {
+    float* pv = scratch;
+    int* pi = reinterpret_cast<int*>(scratch + Q3_ARGMAX_WGS);
+    hipLaunchKernelGGL(k_argmax_part, dim3(Q3_ARGMAX_WGS), dim3(256), 0, st, logits, n, pv, pi);
+    hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(64), 0, st, pv, pi, out, out2);
 }
 
 __global__ __launch_bounds__(64) void k_rmsnorm(float* out, const float* x, const float* w, int n) {

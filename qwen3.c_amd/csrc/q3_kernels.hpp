@@ -28,6 +28,9 @@ struct Gemv {
     const float* nw;   // PRO_NORM: RMSNorm weight [n]
     // epilogue output: EPI_STORE out[d]; EPI_RESID out[d] += ; EPI_SWIGLU out[d/2]
     float* out;
+    // profiling only (else null): clk[0] <- min over workgroups of s_memrealtime at entry,
+    // clk[1] <- max at exit (100 MHz device clock)
+    unsigned long long* clk;
 };
 
 void gemv(const Gemv& g, Pro pro, Epi epi, hipStream_t st);
@@ -61,7 +64,8 @@ void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x,
 // stages) and cs = rope[ctl->pos]
 void begin_step(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, const float* rope,
                 int hd, float* cs, hipStream_t st);
-void argmax(const float* logits, int n, int* out, int* out2, hipStream_t st);
+// scratch: 256 words of device memory
+void argmax(const float* logits, int n, float* scratch, int* out, int* out2, hipStream_t st);
 void set_ctl(Ctl* ctl, const int* tok_src, int tok_imm, int pos, hipStream_t st);
 
 // stand-alone ops behind the reference's exported symbols / the op-level tests
