@@ -178,6 +178,9 @@ void q3_pipeline_shutdown(void);
 
 /* diagnostic builds (-DQ3_ATTN_STAMPS, Q3_STAMPS=1): time stamps of the attention kernel */
 int q3_debug_stamps(Model* m, unsigned long long* out, int n);
+/* Diagnostic: mean microseconds per launch of `iters` back-to-back launches of one GEMV class
+ * ("qkv", "wo", "gateup", "down") cycling over layers [l_lo, l_hi). */
+double q3_debug_gemv_loop(Model* m, const char* which, int l_lo, int l_hi, int iters);
 
 const char* q3_version(void);
 

@@ -117,8 +117,9 @@ __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks
     }
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
+// HPW = query heads a wave may own (1 when the group has at most 4 query heads)
+template <int HD, int HPW>
+__global__ __launch_bounds__(256, 2) void k_attn(Attn a, int multi) {
     constexpr int L4 = HD / 4;               // lanes holding one head as float4
     constexpr int CH = Q3_ATT_CHUNK;
     constexpr int NLD = CH * L4 / 256;       // float4 loads per thread per tile
@@ -136,34 +137,50 @@ __global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
 
     STAMP(0);
     // ---- everything that can be requested before any arithmetic ------------------
+    // Request order = the order the data is needed (a CU returns loads in issue order and takes
+    // in only ~40 KB of requests at once): the K tile (32 KB at head_dim 128), the step's raw
+    // q/k/v + norm weights + (cos,sin) row, and LAST the V tile, which streams in while the
+    // scores and the softmax of this chunk are being computed.
     const int pos = a.ctl->pos;
     float4 kt[NLD], vt[NLD];
     // Slot 0 always has work (chunk 0), so it requests its tile before `pos` has even arrived;
     // the other slots first learn whether their chunk exists -- a speculative 64 KB per idle
     // workgroup would cost tens of MB of useless HBM reads per layer at short contexts.
     if (blockIdx.y != 0 && (int)blockIdx.y * CH > pos) return;
-    {
-        const int t0 = (int)blockIdx.y * CH;    // rows beyond pos are loaded but never used
+    const int tfirst = (int)blockIdx.y * CH;    // rows beyond pos are loaded but never used
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int idx = tid + k * 256;
-            const int t = idx / L4, l4 = idx - t * L4;
-            kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
-            vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
-        }
+    for (int k = 0; k < NLD; k++) {
+        const int idx = tid + k * 256;
+        const int t = idx / L4, l4 = idx - t * L4;
+        kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
     }
-    float4 kraw = make_float4(0.f, 0.f, 0.f, 0.f), vraw = kraw, qraw = kraw, qg = kraw, kg = kraw;
+    float4 kraw = make_float4(0.f, 0.f, 0.f, 0.f), vraw = kraw, qg = kraw, kg = kraw;
+    float4 qraw[HPW];
+#pragma unroll
+    for (int hi = 0; hi < HPW; hi++) qraw[hi] = kraw;      // zeros
     float4 ca = kraw, cb = kraw;
     if (lane < L4) {
         kraw = *reinterpret_cast<const float4*>(a.qkv + P + (size_t)g * HD + 4 * lane);
         vraw = *reinterpret_cast<const float4*>(a.qkv + P + KVD + (size_t)g * HD + 4 * lane);
-        if (wave < kv_mul) qraw = *reinterpret_cast<const float4*>(a.qkv + (size_t)(g * kv_mul + wave) * HD + 4 * lane);
+#pragma unroll
+        for (int hi = 0; hi < HPW; hi++) {
+            const int i = wave + 4 * hi;
+            if (i < kv_mul) qraw[hi] = *reinterpret_cast<const float4*>(a.qkv + (size_t)(g * kv_mul + i) * HD + 4 * lane);
+        }
         if (!a.prepared) {
             qg = *reinterpret_cast<const float4*>(a.qnw + 4 * lane);
             kg = *reinterpret_cast<const float4*>(a.knw + 4 * lane);
         }
     }
     if (!a.prepared) rope_slices<HD>(a.cs, lane, ca, cb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int idx = tid + k * 256;
+        const int t = idx / L4, l4 = idx - t * L4;
+        vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     const int T = pos + 1;
     const int nchunks = (T + CH - 1) / CH;
@@ -179,6 +196,43 @@ __global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
         *reinterpret_cast<float4*>(a.kc + cbase + (size_t)pos * HD + 4 * lane) = kcur;
         *reinterpret_cast<float4*>(a.vc + cbase + (size_t)pos * HD + 4 * lane) = vraw;
     }
+    // slice (tid % L4) of kcur / vraw in every lane, for the tile stores below
+    float4 kcur_m = kcur, vraw_m = vraw;
+    if (L4 == 32) {
+        const float kx = lane_xor_f<32>(kcur.x), ky = lane_xor_f<32>(kcur.y), kz = lane_xor_f<32>(kcur.z), kw = lane_xor_f<32>(kcur.w);
+        const float vx = lane_xor_f<32>(vraw.x), vy = lane_xor_f<32>(vraw.y), vz = lane_xor_f<32>(vraw.z), vw = lane_xor_f<32>(vraw.w);
+        if (half) {
+            kcur_m = make_float4(kx, ky, kz, kw);
+            vraw_m = make_float4(vx, vy, vz, vw);
+        }
+    } else {
+        static_assert(L4 == 32 || L4 == 16, "head_dim 128 or 64");
+        // L4 == 16: lane's slice is lane % 16; lanes 16..63 fetch it from lane % 16
+        const int src = (lane & 15) << 2;
+        kcur_m.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(kcur.x)));
+        kcur_m.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(kcur.y)));
+        kcur_m.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(kcur.z)));
+        kcur_m.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(kcur.w)));
+        vraw_m.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(vraw.x)));
+        vraw_m.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(vraw.y)));
+        vraw_m.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(vraw.z)));
+        vraw_m.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(vraw.w)));
+    }
+    // q of this wave's head(s): norm + rope in lanes [0, L4), then mirrored into the upper half
+    float4 q4[HPW];
+#pragma unroll
+    for (int hi = 0; hi < HPW; hi++) {
+        q4[hi] = qraw[hi];
+        const int i = wave + 4 * hi;
+        if (i < kv_mul) {
+            if (!a.prepared) q4[hi] = headnorm_rope_vals<HD>(q4[hi], qg, ca, cb, lane);
+            if (a.qdbg && blockIdx.y == 0 && lane < L4)
+                *reinterpret_cast<float4*>(a.qdbg + (size_t)(g * kv_mul + i) * HD + 4 * lane) = q4[hi];
+            const float ox = lane_xor_f<32>(q4[hi].x), oy = lane_xor_f<32>(q4[hi].y);
+            const float oz = lane_xor_f<32>(q4[hi].z), ow = lane_xor_f<32>(q4[hi].w);
+            if (half) q4[hi] = make_float4(ox, oy, oz, ow);
+        }
+    }
 
     STAMP(2);
     const float root = sqrtf((float)HD);
@@ -186,133 +240,157 @@ __global__ __launch_bounds__(256) void k_attn(Attn a, int multi) {
     for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
         const int t0 = c * CH;
         const int Tc = (T - t0 < CH) ? T - t0 : CH;      // valid positions in this chunk
-        if (!first) {
+        if (!first) {      // contexts beyond gridDim.y chunks only: the previous chunk's PV is over for this wave
+            // (whole tiles, unconditionally: the cache is padded to a multiple of CH rows, and
+            // predicated accesses would push kt / vt out of registers)
 #pragma unroll
             for (int k = 0; k < NLD; k++) {
                 const int idx = tid + k * 256;
                 const int t = idx / L4, l4 = idx - t * L4;
-                if (t < Tc) {
-                    kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
-                    vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
-                }
+                kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
             }
-            __syncthreads();      // the previous chunk's tiles are no longer being read
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const int idx = tid + k * 256;
+                const int t = idx / L4, l4 = idx - t * L4;
+                vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         first = false;
+        // ---- K tile -> LDS (every wave is past the scores of the previous chunk: barrier V below).
+        // The row of this very step comes from registers (select, no branch: the thread that
+        // owns slice l4 of that row holds the same slice of kcur).
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
             const int idx = tid + k * 256;
             const int t = idx / L4, l4 = idx - t * L4;
-            if (t0 + t != pos) {      // the row of this very step comes from registers below
-                *reinterpret_cast<float4*>(Ks + t * HD + 4 * l4) = kt[k];
-                *reinterpret_cast<float4*>(Vs + t * HD + 4 * l4) = vt[k];
-            }
+            const bool cur = (t0 + t == pos);
+            float4 w = kt[k];
+            w.x = cur ? kcur_m.x : w.x;
+            w.y = cur ? kcur_m.y : w.y;
+            w.z = cur ? kcur_m.z : w.z;
+            w.w = cur ? kcur_m.w : w.w;
+            *reinterpret_cast<float4*>(Ks + t * HD + 4 * l4) = w;
         }
-        if (wave == 1 && lane < L4 && pos >= t0 && pos < t0 + CH) {
-            *reinterpret_cast<float4*>(Ks + (pos - t0) * HD + 4 * lane) = kcur;
-            *reinterpret_cast<float4*>(Vs + (pos - t0) * HD + 4 * lane) = vraw;
-        }
-        __syncthreads();
+        __syncthreads();                                  // barrier K
         STAMP(3);
 
         const int nsteps = (Tc + 1) >> 1;
-        for (int i = wave; i < kv_mul; i += 4) {
-            const int h = g * kv_mul + i;
-            // q of this head: norm + rope in lanes [0, L4), then mirrored into the upper half
-            float4 q4 = qraw;        // preloaded for the first head of this wave
-            if (i != wave && lane < L4) q4 = *reinterpret_cast<const float4*>(a.qkv + (size_t)h * HD + 4 * lane);
-            if (!a.prepared) q4 = headnorm_rope_vals<HD>(q4, qg, ca, cb, lane);
-            if (a.qdbg && blockIdx.y == 0 && lane < L4) *reinterpret_cast<float4*>(a.qdbg + (size_t)h * HD + 4 * lane) = q4;
-            {
-                const float ox = lane_xor_f<32>(q4.x), oy = lane_xor_f<32>(q4.y);
-                const float oz = lane_xor_f<32>(q4.z), ow = lane_xor_f<32>(q4.w);
-                if (half) q4 = make_float4(ox, oy, oz, ow);
-            }
-            // scores: step s handles position t = 2*s + half; the 4-term chains of all 32
-            // steps are formed first, then ONE transposing butterfly leaves the finished
-            // dot of step l in lane l of each half (= lane 32*half + l of the wave)
-            float cpart[32];
+        float e[HPW], m[HPW], lsum[HPW];
 #pragma unroll
-            for (int blk = 0; blk < 4; blk++) {
-                if (8 * blk < nsteps) {
+        for (int hi = 0; hi < HPW; hi++) {
+            e[hi] = m[hi] = lsum[hi] = 0.0f;
+            if (wave + 4 * hi < kv_mul) {
+                // scores: step s handles position t = 2*s + half; the 4-term chains of all 32
+                // steps are formed first, then ONE transposing butterfly leaves the finished
+                // dot of step l in lane l of each half (= lane 32*half + l of the wave)
+                float cpart[32];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int step = 8 * blk + k;
-                        const int t = 2 * step + half;
-                        float cdot = 0.0f;
-                        if (act) {      // rows >= Tc hold stale bytes; their sums are masked below
-                            const float4 k4 = *reinterpret_cast<const float4*>(Ks + t * HD + 4 * l);
-                            cdot = q4.x * k4.x;
-                            cdot = cdot + q4.y * k4.y;
-                            cdot = cdot + q4.z * k4.z;
-                            cdot = cdot + q4.w * k4.w;
+                for (int blk = 0; blk < 4; blk++) {
+                    if (8 * blk < nsteps) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const int step = 8 * blk + k;
+                            const int t = 2 * step + half;
+                            float cdot = 0.0f;
+                            if (act) {      // rows >= Tc hold stale bytes; their sums are masked below
+                                const float4 k4 = *reinterpret_cast<const float4*>(Ks + t * HD + 4 * l);
+                                cdot = q4[hi].x * k4.x;
+                                cdot = cdot + q4[hi].y * k4.y;
+                                cdot = cdot + q4[hi].z * k4.z;
+                                cdot = cdot + q4[hi].w * k4.w;
+                            }
+                            cpart[step] = cdot;
                         }
-                        cpart[step] = cdot;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) cpart[8 * blk + k] = 0.0f;
+                    }
+                }
+                const float dot = transpose_sum32(cpart, l);
+                const bool valid = (2 * l + half) < Tc;
+                const float mys = valid ? dot / root : -3.0e38f;
+                m[hi] = wave_max(mys);
+                e[hi] = valid ? q3_expf(mys - m[hi]) : 0.0f;
+                lsum[hi] = bfly64(e[hi]);
+            }
+        }
+        STAMP(4);
+        // ---- V tile -> LDS (it has been landing during the scores; every wave is past the
+        //      PV of the previous chunk: barrier K above)
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int idx = tid + k * 256;
+            const int t = idx / L4, l4 = idx - t * L4;
+            const bool cur = (t0 + t == pos);
+            float4 w = vt[k];
+            w.x = cur ? vraw_m.x : w.x;
+            w.y = cur ? vraw_m.y : w.y;
+            w.z = cur ? vraw_m.z : w.z;
+            w.w = cur ? vraw_m.w : w.w;
+            *reinterpret_cast<float4*>(Vs + t * HD + 4 * l4) = w;
+        }
+        __syncthreads();                                  // barrier V
+        STAMP(5);
+#pragma unroll
+        for (int hi = 0; hi < HPW; hi++) {
+            const int i = wave + 4 * hi;
+            if (i < kv_mul) {
+                const int h = g * kv_mul + i;
+                // weighted sum of V: stream `half` takes positions half, half+2, ...
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int blk = 0; blk < 4; blk++) {
+                    if (8 * blk < nsteps) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const int step = 8 * blk + k;
+                            const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e[hi]), step));
+                            const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e[hi]), 32 + step));
+                            const float et = half ? e1 : e0;
+                            const int t = 2 * step + half;
+                            float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (act) v4 = *reinterpret_cast<const float4*>(Vs + t * HD + 4 * l);
+                            const bool on = t < Tc;
+                            acc.x = on ? acc.x + et * v4.x : acc.x;
+                            acc.y = on ? acc.y + et * v4.y : acc.y;
+                            acc.z = on ? acc.z + et * v4.z : acc.z;
+                            acc.w = on ? acc.w + et * v4.w : acc.w;
+                        }
+                    }
+                }
+                STAMP(6);
+                float4 o;
+                o.x = acc.x + lane_xor_f<32>(acc.x);
+                o.y = acc.y + lane_xor_f<32>(acc.y);
+                o.z = acc.z + lane_xor_f<32>(acc.z);
+                o.w = acc.w + lane_xor_f<32>(acc.w);
+                if (multi) {
+                    if (lane < L4) {
+                        // write-through (sc1) stores: another workgroup of this launch reads them
+                        float* pp = a.part + ((size_t)h * a.max_chunks + c) * (HD + 2);
+                        st_sc1_f2(pp + 4 * lane, o.x, o.y);
+                        st_sc1_f2(pp + 4 * lane + 2, o.z, o.w);
+                        if (lane == 0) st_sc1_f2(pp + HD, m[hi], lsum[hi]);
                     }
                 } else {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) cpart[8 * blk + k] = 0.0f;
-                }
-            }
-            STAMP(4);
-            const float dot = transpose_sum32(cpart, l);
-            const bool valid = (2 * l + half) < Tc;
-            const float mys = valid ? dot / root : -3.0e38f;
-            const float m = wave_max(mys);
-            const float e = valid ? q3_expf(mys - m) : 0.0f;
-            const float lsum = bfly64(e);
-            STAMP(5);
-            // weighted sum of V: stream `half` takes positions half, half+2, ...
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int blk = 0; blk < 4; blk++) {
-                if (8 * blk < nsteps) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int step = 8 * blk + k;
-                        const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), step));
-                        const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), 32 + step));
-                        const float et = half ? e1 : e0;
-                        const int t = 2 * step + half;
-                        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (act) v4 = *reinterpret_cast<const float4*>(Vs + t * HD + 4 * l);
-                        const bool on = t < Tc;
-                        acc.x = on ? acc.x + et * v4.x : acc.x;
-                        acc.y = on ? acc.y + et * v4.y : acc.y;
-                        acc.z = on ? acc.z + et * v4.z : acc.z;
-                        acc.w = on ? acc.w + et * v4.w : acc.w;
+                    // q8_quantize of the head output (forward.c:291): 64-wide groups of 16 lanes
+                    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (lane < L4) {
+                        y.x = o.x / lsum[hi];
+                        y.y = o.y / lsum[hi];
+                        y.z = o.z / lsum[hi];
+                        y.w = o.w / lsum[hi];
                     }
-                }
-            }
-            STAMP(6);
-            float4 o;
-            o.x = acc.x + lane_xor_f<32>(acc.x);
-            o.y = acc.y + lane_xor_f<32>(acc.y);
-            o.z = acc.z + lane_xor_f<32>(acc.z);
-            o.w = acc.w + lane_xor_f<32>(acc.w);
-            if (multi) {
-                if (lane < L4) {
-                    // write-through (sc1) stores: another workgroup of this launch reads them
-                    float* pp = a.part + ((size_t)h * a.max_chunks + c) * (HD + 2);
-                    st_sc1_f2(pp + 4 * lane, o.x, o.y);
-                    st_sc1_f2(pp + 4 * lane + 2, o.z, o.w);
-                    if (lane == 0) st_sc1_f2(pp + HD, m, lsum);
-                }
-            } else {
-                // q8_quantize of the head output (forward.c:291): 64-wide groups of 16 lanes
-                float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (lane < L4) {
-                    y.x = o.x / lsum;
-                    y.y = o.y / lsum;
-                    y.z = o.z / lsum;
-                    y.w = o.w / lsum;
-                }
-                float scale;
-                const int packed = quantize_group16(y, scale);
-                if (lane < L4) {
-                    reinterpret_cast<int*>(a.oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
-                    if ((lane & 15) == 0) a.os[((size_t)h * HD + 4 * lane) >> 6] = scale;
-                    if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
+                    float scale;
+                    const int packed = quantize_group16(y, scale);
+                    if (lane < L4) {
+                        reinterpret_cast<int*>(a.oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
+                        if ((lane & 15) == 0) a.os[((size_t)h * HD + 4 * lane) >> 6] = scale;
+                        if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
+                    }
                 }
             }
         }
@@ -342,8 +420,11 @@ void attn(const Attn& a, int chunk_slots, bool multi, hipStream_t st) {
         exit(EXIT_FAILURE);
     }
     dim3 grid(a.n_kv, chunk_slots);
-    if (a.hd == 128) hipLaunchKernelGGL(k_attn<128>, grid, dim3(256), 0, st, a, multi ? 1 : 0);
-    else if (a.hd == 64) hipLaunchKernelGGL(k_attn<64>, grid, dim3(256), 0, st, a, multi ? 1 : 0);
+    const bool two = a.n_heads / a.n_kv > 4;
+    if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn<128, 1>), grid, dim3(256), 0, st, a, multi ? 1 : 0);
+    else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, multi ? 1 : 0);
+    else if (a.hd == 64 && !two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, multi ? 1 : 0);
+    else if (a.hd == 64) hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a, multi ? 1 : 0);
     else {
         fprintf(stderr, "[q3hip] attention: head_dim %d not supported (64 or 128)\n", a.hd);
         exit(EXIT_FAILURE);

@@ -86,16 +86,38 @@ __device__ __forceinline__ float sum256_sq(const float* __restrict__ x, int n, i
     return bfly64((c0 + c1) + (c2 + c3));
 }
 
-// clamp(roundf(x / scale), +-127) as an int (reference src/q8.c:26-27) without paying for
-// an IEEE division per element: x * rcp(scale) is within ~2 ulp (< 4e-5 absolute, |q| <= 127)
-// of the correctly rounded quotient, so unless it lies within 1e-3 of a half-integer both
-// round to the same integer; only in that rare case is the true division carried out.
+// clamp(roundf(x / scale), +-127) (reference src/q8.c:26-27), the slow exact way
+__device__ __forceinline__ int q8_code_exact(float x, float scale) {
+    return (int)fminf(fmaxf(roundf(x / scale), -127.0f), 127.0f);
+}
+
+// The same for four values, packed little-endian, without paying for IEEE divisions:
+// r = x * rcp(scale) is within ~2 ulp (< 4e-5 absolute, |r| <= 127) of the correctly rounded
+// quotient, so unless |r| lies within 1e-3 of a half-integer both round to the same integer,
+// which away from those points is floor(|r| + 0.5) with the sign of x.  Only a lane that holds
+// such a near-tie (fract(|r| + 0.5) within 1e-3 of 0 or 1) carries out the true divisions.
 // The result is the reference's in every case.
-__device__ __forceinline__ int q8_code(float x, float scale, float inv) {
-    float r = x * inv;
-    const float fr = fabsf(r - truncf(r));
-    if (fabsf(fr - 0.5f) < 1e-3f || !(fabsf(r) < 1.0e6f)) r = x / scale;
-    return (int)fminf(fmaxf(roundf(r), -127.0f), 127.0f);
+__device__ __forceinline__ int q8_pack4(float4 y, float scale, float inv) {
+    const float t0 = fabsf(y.x * inv) + 0.5f, t1 = fabsf(y.y * inv) + 0.5f;
+    const float t2 = fabsf(y.z * inv) + 0.5f, t3 = fabsf(y.w * inv) + 0.5f;
+    const float g0 = fabsf(__builtin_amdgcn_fractf(t0) - 0.5f), g1 = fabsf(__builtin_amdgcn_fractf(t1) - 0.5f);
+    const float g2 = fabsf(__builtin_amdgcn_fractf(t2) - 0.5f), g3 = fabsf(__builtin_amdgcn_fractf(t3) - 0.5f);
+    int q0, q1, q2, q3;
+    // (a denormal scale makes rcp overflow: those groups take the exact path as well)
+    if (__builtin_expect(fmaxf(fmaxf(g0, g1), fmaxf(g2, g3)) > 0.499f || !(scale >= 1e-30f), 0)) {
+        q0 = q8_code_exact(y.x, scale);
+        q1 = q8_code_exact(y.y, scale);
+        q2 = q8_code_exact(y.z, scale);
+        q3 = q8_code_exact(y.w, scale);
+    } else {
+        q0 = (int)copysignf(fminf(floorf(t0), 127.0f), y.x);
+        q1 = (int)copysignf(fminf(floorf(t1), 127.0f), y.y);
+        q2 = (int)copysignf(fminf(floorf(t2), 127.0f), y.z);
+        q3 = (int)copysignf(fminf(floorf(t3), 127.0f), y.w);
+    }
+    const unsigned lo = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x0c0c0400u);
+    const unsigned hi = __builtin_amdgcn_perm((unsigned)q3, (unsigned)q2, 0x0c0c0400u);
+    return (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
 // q8_quantize (reference src/q8.c:5-30) of one 64-wide group held by 16 consecutive
@@ -103,17 +125,14 @@ __device__ __forceinline__ int q8_code(float x, float scale, float inv) {
 // group scale in every lane of the group.
 __device__ __forceinline__ int quantize_group16(float4 y, float& scale) {
     float amax = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
+    // max is exact in any order, so the 16-lane reduction may pair lanes however is cheapest:
+    // DPP quad_perm, then row_half_mirror / row_mirror (no trip through the LDS crossbar)
     amax = fmaxf(amax, lane_xor_f<1>(amax));
     amax = fmaxf(amax, lane_xor_f<2>(amax));
-    amax = fmaxf(amax, lane_xor_f<4>(amax));
-    amax = fmaxf(amax, lane_xor_f<8>(amax));
+    amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0x141, 0xF, 0xF, true)));
+    amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0x140, 0xF, 0xF, true)));
     scale = q3_q8_scale(amax);
-    const float inv = __builtin_amdgcn_rcpf(scale);
-    const int q0 = q8_code(y.x, scale, inv);
-    const int q1 = q8_code(y.y, scale, inv);
-    const int q2 = q8_code(y.z, scale, inv);
-    const int q3 = q8_code(y.w, scale, inv);
-    return (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+    return q8_pack4(y, scale, __builtin_amdgcn_rcpf(scale));
 }
 
 __device__ __forceinline__ int dot16(v4i w, v4i x) {

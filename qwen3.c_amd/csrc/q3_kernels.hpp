@@ -31,6 +31,8 @@ struct Gemv {
     // profiling only (else null): clk[0] <- min over workgroups of s_memrealtime at entry,
     // clk[1] <- max at exit (100 MHz device clock)
     unsigned long long* clk;
+    // diagnostic builds only (-DQ3_GEMV_STAMPS): phase marks of wave 0 of three workgroups
+    unsigned long long* stamps;
 };
 
 void gemv(const Gemv& g, Pro pro, Epi epi, hipStream_t st);

@@ -385,7 +385,7 @@ Dev* attach(Model* m) {
         for (int i = 0; i < 2; i++) d->outbox[i] = dalloc<float>(d, d->dim + 1);
     }
     d->pgexec.assign((size_t)d->n_streams * 2, nullptr);
-    if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 64); HIPCHK(hipMemset(d->stamps, 0, 64 * 8)); }
+    if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 2048); HIPCHK(hipMemset(d->stamps, 0, 2048 * 8)); }
     HIPCHK(hipHostMalloc((void**)&d->ctl_host, sizeof(q3k::Ctl), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&d->amax_host, sizeof(int), hipHostMallocDefault));
     if (m->state.logits) {
@@ -504,11 +504,14 @@ void enqueue_layer(Dev* d, int l, bool multi, int stream = 0) {
     const LayerDev& L = d->layers[l];
     q3k::Gemv g;
     memset(&g, 0, sizeof(g));
+    const char* stamp_which = (d->stamps && l == (d->l0 + d->l1) / 2) ? getenv("Q3_STAMP_GEMV") : nullptr;
+    auto stamp_for = [&](const char* name) { return (stamp_which && !strcmp(stamp_which, name)) ? d->stamps : nullptr; };
     {   // rmsnorm + quantise + Wq|Wk|Wv  (reference forward.c:254-262)
         g.W = L.qkv_q; g.S = L.qkv_s; g.n = d->dim; g.d = d->P + 2 * d->KVD;
         g.xf = d->x; g.nw = L.att_nw; g.out = d->qkv;
         Timed t(d, "qkv", q3_gemv_bytes(g.d, g.n));
         g.clk = t.clk();
+        g.stamps = stamp_for("qkv");
         q3k::gemv(g, q3k::PRO_NORM, q3k::EPI_STORE, d->st);
     }
     {   // head norms + RoPE + cache append + attention + quantise (forward.c:267-291)
@@ -523,6 +526,7 @@ void enqueue_layer(Dev* d, int l, bool multi, int stream = 0) {
         g.xq = d->att_q; g.xs = d->att_s; g.out = d->x;
         Timed t(d, "wo", q3_gemv_bytes(g.d, g.n));
         g.clk = t.clk();
+        g.stamps = stamp_for("wo");
         q3k::gemv(g, q3k::PRO_Q8, q3k::EPI_RESID, d->st);
     }
     {   // rmsnorm + quantise + gate/up + SwiGLU (forward.c:303-321)
@@ -530,6 +534,7 @@ void enqueue_layer(Dev* d, int l, bool multi, int stream = 0) {
         g.xf = d->x; g.nw = L.ffn_nw; g.out = d->h;
         Timed t(d, "gateup", q3_gemv_bytes(g.d, g.n));
         g.clk = t.clk();
+        g.stamps = stamp_for("gateup");
         q3k::gemv(g, q3k::PRO_NORM, q3k::EPI_SWIGLU, d->st);
     }
     {   // quantise + down + residual (forward.c:326-338)
@@ -537,6 +542,7 @@ void enqueue_layer(Dev* d, int l, bool multi, int stream = 0) {
         g.xf = d->h; g.nw = nullptr; g.out = d->x;
         Timed t(d, "down", q3_gemv_bytes(g.d, g.n));
         g.clk = t.clk();
+        g.stamps = stamp_for("down");
         q3k::gemv(g, q3k::PRO_F32, q3k::EPI_RESID, d->st);
     }
     if (d->tap) {
@@ -685,8 +691,51 @@ int q3_debug_stamps(Model* m, unsigned long long* out, int n) {
     Dev* d = lookup(m);
     if (!d || !d->stamps) return 0;
     HIPCHK(hipStreamSynchronize(d->st));
-    HIPCHK(hipMemcpy(out, d->stamps, (size_t)(n < 64 ? n : 64) * 8, hipMemcpyDeviceToHost));
-    return n < 64 ? n : 64;
+    HIPCHK(hipMemcpy(out, d->stamps, (size_t)(n < 2048 ? n : 2048) * 8, hipMemcpyDeviceToHost));
+    return n < 2048 ? n : 2048;
+}
+
+// diagnostic: `iters` back-to-back launches of one GEMV class cycling over layers [l_lo, l_hi),
+// HIP-event timed as a whole; mean microseconds per launch.  With l_hi == l_lo + 1 the same
+// weights are re-read every launch (Infinity-Cache resident), otherwise each launch streams fresh ones.
+double q3_debug_gemv_loop(Model* m, const char* which, int l_lo, int l_hi, int iters) {
+    Dev* d = lookup(m);
+    if (!d || l_lo < d->l0 || l_hi > d->l1 || l_hi <= l_lo || iters <= 0) return -1.0;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int pass = 0; pass < 2; pass++) {      // pass 0 warms up
+        HIPCHK(hipEventRecord(e0, d->st));
+        for (int i = 0; i < iters; i++) {
+            const LayerDev& L = d->layers[l_lo + i % (l_hi - l_lo)];
+            q3k::Gemv g;
+            memset(&g, 0, sizeof(g));
+            if (!strcmp(which, "qkv")) {
+                g.W = L.qkv_q; g.S = L.qkv_s; g.n = d->dim; g.d = d->P + 2 * d->KVD;
+                g.xf = d->x; g.nw = L.att_nw; g.out = d->qkv;
+                q3k::gemv(g, q3k::PRO_NORM, q3k::EPI_STORE, d->st);
+            } else if (!strcmp(which, "wo")) {
+                g.W = L.wo_q; g.S = L.wo_s; g.n = d->P; g.d = d->dim;
+                g.xq = d->att_q; g.xs = d->att_s; g.out = d->qkv;       // scratch output
+                q3k::gemv(g, q3k::PRO_Q8, q3k::EPI_STORE, d->st);
+            } else if (!strcmp(which, "gateup")) {
+                g.W = L.gu_q; g.S = L.gu_s; g.n = d->dim; g.d = 2 * d->hid;
+                g.xf = d->x; g.nw = L.ffn_nw; g.out = d->h;
+                q3k::gemv(g, q3k::PRO_NORM, q3k::EPI_SWIGLU, d->st);
+            } else {
+                g.W = L.dn_q; g.S = L.dn_s; g.n = d->hid; g.d = d->dim;
+                g.xf = d->h; g.nw = nullptr; g.out = d->qkv;
+                q3k::gemv(g, q3k::PRO_F32, q3k::EPI_STORE, d->st);
+            }
+        }
+        HIPCHK(hipEventRecord(e1, d->st));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    HIPCHK(hipEventDestroy(e0));
+    HIPCHK(hipEventDestroy(e1));
+    return (double)ms * 1e3 / iters;
 }
 
 int q3_device_count(void) {

@@ -12,6 +12,11 @@
 #pragma once
 #include "q3_device.hpp"
 
+// cache policy of the weight stream: 2 = nt (read once, do not keep)
+#ifndef Q3_W_AUX
+#define Q3_W_AUX 2
+#endif
+
 namespace q3k {
 
 template <int R, int NJ>
@@ -57,13 +62,41 @@ __device__ __forceinline__ void tile_issue(Tile<R, NJ>& t, const WView& wv, int 
             if (j < NJ - 1 || voff < tail) {
                 // the constant part below 4 KiB rides in the instruction's immediate offset, so a
                 // row needs one scalar offset per 4 KiB of codes and one for its scales
-                w = __builtin_amdgcn_raw_buffer_load_b128(wv.w, voff + (j & 3) * 1024, wbase + (j >> 2) * 4096, 2 /* nt */);
-                s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wv.s, vsoff + j * 64, sbase, 2));
+                w = __builtin_amdgcn_raw_buffer_load_b128(wv.w, voff + (j & 3) * 1024, wbase + (j >> 2) * 4096, Q3_W_AUX);
+                s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wv.s, vsoff + j * 64, sbase, Q3_W_AUX));
             }
             t.w[r][j] = w;
             t.s[r][j] = s;
         }
     }
+}
+
+// The same loads one at a time, for kernels that interleave issue and use.  Branch-free: lanes
+// past the end of a row get an offset beyond num_records (the load returns zero and moves no
+// bytes), so the compiler sees straight-line code and counts vmcnt exactly.
+struct TileLane {
+    int voff, voff_last, vsoff, vsoff_last;
+};
+template <int NJ>
+__device__ __forceinline__ TileLane tile_lane(const WView& wv, int lane) {
+    asm volatile("" : "+v"(lane));
+    constexpr int OOB = 0x7ffff000;
+    const int tail = wv.n - (NJ - 1) * 1024;
+    TileLane t;
+    t.voff = lane * 16;
+    t.vsoff = (lane >> 2) * 4;
+    t.voff_last = t.voff < tail ? t.voff : OOB;
+    t.vsoff_last = t.voff < tail ? t.vsoff : OOB;
+    return t;
+}
+template <int R, int NJ>
+__device__ __forceinline__ void tile_issue_one(Tile<R, NJ>& t, const WView& wv, const TileLane& tl, int row0, int r, int j) {
+    const int n = wv.n, ngroups = wv.n >> 6;
+    const int wbase = (row0 + r) * n + (j >> 2) * 4096;
+    const int sbase = (row0 + r) * ngroups * 4;
+    const bool last = j == NJ - 1;
+    t.w[r][j] = __builtin_amdgcn_raw_buffer_load_b128(wv.w, (last ? tl.voff_last : tl.voff) + (j & 3) * 1024, wbase, Q3_W_AUX);
+    t.s[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wv.s, (last ? tl.vsoff_last : tl.vsoff) + j * 64, sbase, Q3_W_AUX));
 }
 
 // acc[r] = row r of the tile . activation; every lane ends with the full sums.

@@ -130,7 +130,7 @@ def host_lib():
 def hip_lib():
     """The product library.  Raises if it is missing: there is no fallback."""
     if "hip" not in _cache:
-        path = os.path.join(PKG, "libq3hip.so")
+        path = os.environ.get("Q3_LIB") or os.path.join(PKG, "libq3hip.so")   # Q3_LIB: diagnostic variants
         if not os.path.exists(path):
             raise RuntimeError("libq3hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         lib = _bind_host(C.CDLL(path))
@@ -221,6 +221,8 @@ def hip_lib():
         lib.q3_pipeline_selftest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         lib.q3_pipeline_allreduce_max.restype = C.c_double
         lib.q3_pipeline_allreduce_max.argtypes = [C.c_double]
+        lib.q3_debug_gemv_loop.restype = C.c_double
+        lib.q3_debug_gemv_loop.argtypes = [ModelP, C.c_char_p, C.c_int, C.c_int, C.c_int]
         lib.q3_debug_stamps.restype = C.c_int
         lib.q3_debug_stamps.argtypes = [ModelP, C.POINTER(C.c_uint64), C.c_int]
         lib.q3_pipeline_shutdown.restype = None

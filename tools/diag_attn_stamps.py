@@ -1,8 +1,9 @@
 import sys, os, ctypes as C
-sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 os.environ["Q3_STAMPS"] = "1"
 if len(sys.argv) > 2: os.environ["HIP_FORCE_DEV_KERNARG"] = sys.argv[2]
 os.environ["Q3_GRAPH"] = sys.argv[1] if len(sys.argv) > 1 else "1"
+os.environ.setdefault("Q3_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qwen3.c_amd", "build_astamps", "libq3hip.so"))
 import numpy as np, q3lib as Q
 hip = Q.hip_lib()
 os.makedirs("/tmp/q3", exist_ok=True); path = "/tmp/q3/4B.bin"; Q.synth("4B", path)
