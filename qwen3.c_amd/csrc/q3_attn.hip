@@ -54,12 +54,34 @@ __device__ __forceinline__ float2 ld_sc1_f2(const float* p) {
 // forces the LOADS to be: the (m_c, l_c) pairs are fetched 64 chunks at a time (one per lane)
 // and the O_c rows eight chunks ahead of the accumulation.
 template <int HD>
+__device__ __forceinline__ float4 ld_partial_row(const float* base, int c, int lane) {
+    constexpr int ST = HD + 2;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < HD / 4) {
+        const float* pp = base + (size_t)c * ST + 4 * lane;
+        const float2 lo = ld_sc1_f2(pp);
+        const float2 hi = ld_sc1_f2(pp + 2);
+        o = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+    return o;
+}
+
+template <int HD>
 __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks, int lane) {
     constexpr int L4 = HD / 4;
     constexpr int ST = HD + 2;
+    constexpr int AH = 8;                 // O_c rows requested ahead of the accumulation
     const float* base = a.part + (size_t)h * a.max_chunks * ST;
-    float M = -3.0e38f;
-    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+    // Everything the first 64 chunks need is requested in ONE burst -- their (m_c, l_c) pairs,
+    // one per lane, and the first AH rows O_c -- so the usual context (<= 4096 positions)
+    // costs a single memory round trip before the arithmetic starts.
+    float2 ml0 = make_float2(-3.0e38f, 0.0f);
+    if (lane < nchunks) ml0 = ld_sc1_f2(base + (size_t)lane * ST + HD);
+    float4 o[AH];
+#pragma unroll
+    for (int k = 0; k < AH; k++) o[k] = ld_partial_row<HD>(base, k < nchunks ? k : nchunks - 1, lane);
+    float M = wave_max(ml0.x);
+    for (int c0 = 64; c0 < nchunks; c0 += 64) {
         const int c = c0 + lane;
         const float mc = c < nchunks ? ld_sc1_f2(base + (size_t)c * ST + HD).x : -3.0e38f;
         M = fmaxf(M, wave_max(mc));
@@ -68,27 +90,21 @@ __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks
     float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c0 = 0; c0 < nchunks; c0 += 64) {
         const int c = c0 + lane;
+        float2 ml = ml0;
+        if (c0 > 0) ml = c < nchunks ? ld_sc1_f2(base + (size_t)c * ST + HD) : make_float2(-3.0e38f, 0.0f);
         float wc = 0.0f, wl = 0.0f;
         if (c < nchunks) {
-            const float2 ml = ld_sc1_f2(base + (size_t)c * ST + HD);
             wc = q3_expf(ml.x - M);
             wl = wc * ml.y;
         }
         const int cnt = (nchunks - c0 < 64) ? nchunks - c0 : 64;
-        for (int k0 = 0; k0 < cnt; k0 += 8) {
-            float4 o[8];
+        for (int k0 = 0; k0 < cnt; k0 += AH) {
+            float4 nx[AH];                 // the next AH rows, requested before this group is consumed
+            const int nb = c0 + k0 + AH;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k0 + k < cnt && lane < L4) {
-                    const float* pp = base + (size_t)(c0 + k0 + k) * ST + 4 * lane;
-                    const float2 lo = ld_sc1_f2(pp);
-                    const float2 hi = ld_sc1_f2(pp + 2);
-                    o[k] = make_float4(lo.x, lo.y, hi.x, hi.y);
-                }
-            }
+            for (int k = 0; k < AH; k++) nx[k] = (nb < nchunks) ? ld_partial_row<HD>(base, nb + k < nchunks ? nb + k : nchunks - 1, lane) : o[k];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < AH; k++) {
                 if (k0 + k < cnt) {
                     const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wc), (k0 + k) & 63));
                     const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), (k0 + k) & 63));
@@ -99,6 +115,8 @@ __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks
                     A.w = A.w + w * o[k].w;
                 }
             }
+#pragma unroll
+            for (int k = 0; k < AH; k++) o[k] = nx[k];
         }
     }
     float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -138,9 +156,9 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a, int multi) {
     STAMP(0);
     // ---- everything that can be requested before any arithmetic ------------------
     // Request order = the order the data is needed (a CU returns loads in issue order and takes
-    // in only ~40 KB of requests at once): the K tile (32 KB at head_dim 128), the step's raw
-    // q/k/v + norm weights + (cos,sin) row, and LAST the V tile, which streams in while the
-    // scores and the softmax of this chunk are being computed.
+    // in only ~40 KB of requests at once): the step's raw q/k/v + norm weights + (cos,sin) row,
+    // the K tile (32 KB at head_dim 128), which lands while the head norms run, and after the
+    // norms the V tile, which streams in while the scores and the softmax are being computed.
     const int pos = a.ctl->pos;
     float4 kt[NLD], vt[NLD];
     // Slot 0 always has work (chunk 0), so it requests its tile before `pos` has even arrived;
@@ -148,18 +166,26 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a, int multi) {
     // workgroup would cost tens of MB of useless HBM reads per layer at short contexts.
     if (blockIdx.y != 0 && (int)blockIdx.y * CH > pos) return;
     const int tfirst = (int)blockIdx.y * CH;    // rows beyond pos are loaded but never used
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-        const int idx = tid + k * 256;
-        const int t = idx / L4, l4 = idx - t * L4;
-        kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
-    }
+    // At head_dim 128 a head is 32 lanes of float4, so ONE norm + rope pass serves two heads:
+    // k of this step in the lower half of the wave, the wave's (first) query head in the upper
+    // half (bfly32 inside a half adds exactly what bfly64 adds when the other half is zero).
+    constexpr bool FUSE = (L4 == 32);
     float4 kraw = make_float4(0.f, 0.f, 0.f, 0.f), vraw = kraw, qg = kraw, kg = kraw;
     float4 qraw[HPW];
 #pragma unroll
     for (int hi = 0; hi < HPW; hi++) qraw[hi] = kraw;      // zeros
     float4 ca = kraw, cb = kraw;
-    if (lane < L4) {
+    if constexpr (FUSE) {
+        if (!half) kraw = *reinterpret_cast<const float4*>(a.qkv + P + (size_t)g * HD + 4 * l);
+        if (half && wave < kv_mul) kraw = *reinterpret_cast<const float4*>(a.qkv + (size_t)(g * kv_mul + wave) * HD + 4 * l);
+        vraw = *reinterpret_cast<const float4*>(a.qkv + P + KVD + (size_t)g * HD + 4 * l);     // slice l in both halves
+        if (HPW > 1 && lane < L4 && wave + 4 < kv_mul)
+            qraw[HPW - 1] = *reinterpret_cast<const float4*>(a.qkv + (size_t)(g * kv_mul + wave + 4) * HD + 4 * lane);
+        if (!a.prepared) {
+            kg = *reinterpret_cast<const float4*>((half ? a.qnw : a.knw) + 4 * l);
+            if (HPW > 1 && lane < L4) qg = *reinterpret_cast<const float4*>(a.qnw + 4 * lane);
+        }
+    } else if (lane < L4) {
         kraw = *reinterpret_cast<const float4*>(a.qkv + P + (size_t)g * HD + 4 * lane);
         vraw = *reinterpret_cast<const float4*>(a.qkv + P + KVD + (size_t)g * HD + 4 * lane);
 #pragma unroll
@@ -172,13 +198,13 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a, int multi) {
             kg = *reinterpret_cast<const float4*>(a.knw + 4 * lane);
         }
     }
-    if (!a.prepared) rope_slices<HD>(a.cs, lane, ca, cb);
+    if (!a.prepared) rope_slices<HD>(a.cs, FUSE ? l : lane, ca, cb);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
         const int idx = tid + k * 256;
         const int t = idx / L4, l4 = idx - t * L4;
-        vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
+        kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -188,27 +214,30 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a, int multi) {
     STAMP(1);
     const bool owner = ((nchunks - 1) % (int)gridDim.y) == (int)blockIdx.y;
 
-    // k of this step: norm + rope, every wave redundantly (no barrier); wave 0 of the
-    // owning workgroup appends k and v to the cache
-    float4 kcur = kraw;
-    if (!a.prepared) kcur = headnorm_rope_vals<HD>(kraw, kg, ca, cb, lane);
-    if (owner && wave == 0 && lane < L4) {
-        *reinterpret_cast<float4*>(a.kc + cbase + (size_t)pos * HD + 4 * lane) = kcur;
-        *reinterpret_cast<float4*>(a.vc + cbase + (size_t)pos * HD + 4 * lane) = vraw;
-    }
-    // slice (tid % L4) of kcur / vraw in every lane, for the tile stores below
-    float4 kcur_m = kcur, vraw_m = vraw;
-    if (L4 == 32) {
-        const float kx = lane_xor_f<32>(kcur.x), ky = lane_xor_f<32>(kcur.y), kz = lane_xor_f<32>(kcur.z), kw = lane_xor_f<32>(kcur.w);
-        const float vx = lane_xor_f<32>(vraw.x), vy = lane_xor_f<32>(vraw.y), vz = lane_xor_f<32>(vraw.z), vw = lane_xor_f<32>(vraw.w);
-        if (half) {
-            kcur_m = make_float4(kx, ky, kz, kw);
-            vraw_m = make_float4(vx, vy, vz, vw);
+    // k of this step (every wave redundantly, no barrier) and q of this wave's head(s):
+    // norm + rope; kcur_m / vraw_m / q4 end up as slice (tid % L4) in every lane
+    float4 kcur_m, vraw_m = vraw, q4[HPW];
+    if constexpr (FUSE) {
+        float4 r = kraw;
+        if (!a.prepared) r = headnorm_rope_halves<HD>(kraw, kg, ca, cb, l);
+        const float ox = lane_xor_f<32>(r.x), oy = lane_xor_f<32>(r.y), oz = lane_xor_f<32>(r.z), ow = lane_xor_f<32>(r.w);
+        const float4 other = make_float4(ox, oy, oz, ow);
+        kcur_m = half ? other : r;
+        q4[0] = half ? r : other;
+        if (HPW > 1) {
+            q4[HPW - 1] = qraw[HPW - 1];
+            if (wave + 4 < kv_mul) {
+                if (!a.prepared) q4[HPW - 1] = headnorm_rope_vals<HD>(q4[HPW - 1], qg, ca, cb, lane);
+                const float ax = lane_xor_f<32>(q4[HPW - 1].x), ay = lane_xor_f<32>(q4[HPW - 1].y);
+                const float az = lane_xor_f<32>(q4[HPW - 1].z), aw = lane_xor_f<32>(q4[HPW - 1].w);
+                if (half) q4[HPW - 1] = make_float4(ax, ay, az, aw);
+            }
         }
     } else {
-        static_assert(L4 == 32 || L4 == 16, "head_dim 128 or 64");
+        float4 kcur = kraw;
+        if (!a.prepared) kcur = headnorm_rope_vals<HD>(kraw, kg, ca, cb, lane);
         // L4 == 16: lane's slice is lane % 16; lanes 16..63 fetch it from lane % 16
-        const int src = (lane & 15) << 2;
+        const int src = (lane & (L4 - 1)) << 2;
         kcur_m.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(kcur.x)));
         kcur_m.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(kcur.y)));
         kcur_m.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(kcur.z)));
@@ -217,21 +246,36 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a, int multi) {
         vraw_m.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(vraw.y)));
         vraw_m.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(vraw.z)));
         vraw_m.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(vraw.w)));
-    }
-    // q of this wave's head(s): norm + rope in lanes [0, L4), then mirrored into the upper half
-    float4 q4[HPW];
 #pragma unroll
-    for (int hi = 0; hi < HPW; hi++) {
-        q4[hi] = qraw[hi];
-        const int i = wave + 4 * hi;
-        if (i < kv_mul) {
-            if (!a.prepared) q4[hi] = headnorm_rope_vals<HD>(q4[hi], qg, ca, cb, lane);
-            if (a.qdbg && blockIdx.y == 0 && lane < L4)
-                *reinterpret_cast<float4*>(a.qdbg + (size_t)(g * kv_mul + i) * HD + 4 * lane) = q4[hi];
-            const float ox = lane_xor_f<32>(q4[hi].x), oy = lane_xor_f<32>(q4[hi].y);
-            const float oz = lane_xor_f<32>(q4[hi].z), ow = lane_xor_f<32>(q4[hi].w);
-            if (half) q4[hi] = make_float4(ox, oy, oz, ow);
+        for (int hi = 0; hi < HPW; hi++) {
+            q4[hi] = qraw[hi];
+            if (wave + 4 * hi < kv_mul) {
+                if (!a.prepared) q4[hi] = headnorm_rope_vals<HD>(q4[hi], qg, ca, cb, lane);
+                const float ox = lane_xor_f<32>(q4[hi].x), oy = lane_xor_f<32>(q4[hi].y);
+                const float oz = lane_xor_f<32>(q4[hi].z), ow = lane_xor_f<32>(q4[hi].w);
+                if (half) q4[hi] = make_float4(ox, oy, oz, ow);
+            }
         }
+    }
+    // now the V tile: the K tile has landed (loads return in order), so these requests find
+    // room in the CU's queue instead of parking the wave in the issue stage
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int idx = tid + k * 256;
+        const int t = idx / L4, l4 = idx - t * L4;
+        vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // wave 0 of the owning workgroup appends k and v of this step to the cache
+    if (owner && wave == 0 && lane < L4) {
+        *reinterpret_cast<float4*>(a.kc + cbase + (size_t)pos * HD + 4 * lane) = kcur_m;
+        *reinterpret_cast<float4*>(a.vc + cbase + (size_t)pos * HD + 4 * lane) = vraw_m;
+    }
+    if (a.qdbg && blockIdx.y == 0 && lane < L4) {
+#pragma unroll
+        for (int hi = 0; hi < HPW; hi++)
+            if (wave + 4 * hi < kv_mul) *reinterpret_cast<float4*>(a.qdbg + (size_t)(g * kv_mul + wave + 4 * hi) * HD + 4 * lane) = q4[hi];
     }
 
     STAMP(2);
@@ -341,6 +385,21 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a, int multi) {
                 const int h = g * kv_mul + i;
                 // weighted sum of V: stream `half` takes positions half, half+2, ...
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (Tc == CH) {       // full chunk: no masking (same sums: every position is on)
+#pragma unroll
+                    for (int step = 0; step < CH / 2; step++) {
+                        if ((step & 7) == 0) __builtin_amdgcn_sched_barrier(0);   // eight LDS reads in flight, not 32
+                        const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e[hi]), step));
+                        const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e[hi]), 32 + step));
+                        const float et = half ? e1 : e0;
+                        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (act) v4 = *reinterpret_cast<const float4*>(Vs + (2 * step + half) * HD + 4 * l);
+                        acc.x = acc.x + et * v4.x;
+                        acc.y = acc.y + et * v4.y;
+                        acc.z = acc.z + et * v4.z;
+                        acc.w = acc.w + et * v4.w;
+                    }
+                } else
 #pragma unroll
                 for (int blk = 0; blk < 4; blk++) {
                     if (8 * blk < nsteps) {
@@ -394,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a, int multi) {
                 }
             }
         }
-        if (multi) {
+        if (multi == ATT_MERGE) {
             // Publish: every storing wave drains its write-through stores, the workgroup meets,
             // ONE lane takes a ticket (Guideline 16, counter form).  The workgroup whose ticket
             // is the last of its kv head merges the partials of the head's chunks right here.
@@ -414,20 +473,85 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a, int multi) {
     STAMP(7);
 }
 
-void attn(const Attn& a, int chunk_slots, bool multi, hipStream_t st) {
+// ---- ATT_LONG: merge of the chunk partials as its own launch ---------------------------
+// One wave per 64 consecutive output values (= one quantisation group; HD/64 waves per head),
+// lane = one value.  The sums over chunks are sequential by contract (q3_numerics.h), but every
+// lane owns its own chain and all the loads of 32 chunks are in flight together.
+__device__ __forceinline__ int q8_code1(float y, float scale, float inv) {
+    const float t = fabsf(y * inv) + 0.5f;
+    const float gg = fabsf(__builtin_amdgcn_fractf(t) - 0.5f);
+    if (__builtin_expect(gg > 0.499f || !(scale >= 1e-30f), 0)) return q8_code_exact(y, scale);
+    return (int)copysignf(fminf(floorf(t), 127.0f), y);
+}
+template <int HD>
+__global__ __launch_bounds__(64) void k_attn_merge(Attn a) {
+    constexpr int ST = HD + 2;
+    constexpr int GPH = HD / 64;                // quantisation groups per head
+    const int h = blockIdx.x / GPH, grp = blockIdx.x % GPH;
+    const int lane = threadIdx.x;
+    const int nchunks = a.ctl->pos / Q3_ATT_CHUNK + 1;
+    const float* base = a.part + (size_t)h * a.max_chunks * ST;
+    const int d = grp * 64 + lane;
+    float M = -3.0e38f;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        const int c = c0 + lane;
+        const float mc = c < nchunks ? base[(size_t)c * ST + HD] : -3.0e38f;
+        M = fmaxf(M, wave_max(mc));
+    }
+    float L = 0.0f, A = 0.0f;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+        const int c = c0 + lane;
+        float wc = 0.0f, wl = 0.0f;
+        if (c < nchunks) {
+            const float2 ml = *reinterpret_cast<const float2*>(base + (size_t)c * ST + HD);
+            wc = q3_expf(ml.x - M);
+            wl = wc * ml.y;
+        }
+        const int cnt = (nchunks - c0 < 64) ? nchunks - c0 : 64;
+        for (int k0 = 0; k0 < cnt; k0 += 32) {
+            float o[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const int cc = c0 + k0 + k;
+                o[k] = base[(size_t)(cc < nchunks ? cc : nchunks - 1) * ST + d];
+            }
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                if (k0 + k < cnt) {
+                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wc), (k0 + k) & 63));
+                    const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), (k0 + k) & 63));
+                    L = L + t;
+                    A = A + w * o[k];
+                }
+            }
+        }
+    }
+    const float y = A / L;
+    const float scale = q3_q8_scale(wave_max(fabsf(y)));
+    const int q = q8_code1(y, scale, __builtin_amdgcn_rcpf(scale));
+    a.oq[(size_t)h * HD + d] = (int8_t)q;
+    if (lane == 0) a.os[((size_t)h * HD + d) >> 6] = scale;
+    if (a.of) a.of[(size_t)h * HD + d] = y;
+}
+
+void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st) {
     if (a.n_heads / a.n_kv > Q3_MAXG) {
         fprintf(stderr, "[q3hip] attention: more than %d query heads per kv head\n", Q3_MAXG);
         exit(EXIT_FAILURE);
     }
-    dim3 grid(a.n_kv, chunk_slots);
-    const bool two = a.n_heads / a.n_kv > 4;
-    if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn<128, 1>), grid, dim3(256), 0, st, a, multi ? 1 : 0);
-    else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, multi ? 1 : 0);
-    else if (a.hd == 64 && !two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, multi ? 1 : 0);
-    else if (a.hd == 64) hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a, multi ? 1 : 0);
-    else {
+    if (a.hd != 128 && a.hd != 64) {
         fprintf(stderr, "[q3hip] attention: head_dim %d not supported (64 or 128)\n", a.hd);
         exit(EXIT_FAILURE);
+    }
+    dim3 grid(a.n_kv, mode == ATT_SINGLE ? 1 : chunk_slots);
+    const bool two = a.n_heads / a.n_kv > 4;
+    if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn<128, 1>), grid, dim3(256), 0, st, a, (int)mode);
+    else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, (int)mode);
+    else if (!two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, (int)mode);
+    else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a, (int)mode);
+    if (mode == ATT_LONG) {
+        if (a.hd == 128) hipLaunchKernelGGL(k_attn_merge<128>, dim3(a.n_heads * 2), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(k_attn_merge<64>, dim3(a.n_heads), dim3(64), 0, st, a);
     }
 }
 

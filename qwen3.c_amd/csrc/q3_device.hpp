@@ -62,14 +62,19 @@ __device__ __forceinline__ float bfly_quads(float v) {
     v = v + lane_xor_f<4>(v);
     return v;
 }
+// max over the 64 lanes, in every lane.  max is exact in any order, so the cheapest pairing
+// will do: DPP inside each row of 16, then two row broadcasts and a readlane -- no LDS crossbar.
 __device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, lane_xor_f<32>(v));
-    v = fmaxf(v, lane_xor_f<16>(v));
-    v = fmaxf(v, lane_xor_f<8>(v));
-    v = fmaxf(v, lane_xor_f<4>(v));
-    v = fmaxf(v, lane_xor_f<2>(v));
     v = fmaxf(v, lane_xor_f<1>(v));
-    return v;
+    v = fmaxf(v, lane_xor_f<2>(v));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true)));   // row_half_mirror
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true)));   // row_mirror
+    // every lane now holds the max of its row of 16; rows 0..3 -> four readlanes
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // SUM256 of x_i^2 over n floats (n % 4 == 0), computed by ONE wave.
@@ -207,6 +212,45 @@ __device__ __forceinline__ float4 headnorm_rope_vals(float4 v, float4 g, float4 
             r.z = o.z * cb.y + y.z * cb.x;
             r.w = o.w * cb.w + y.w * cb.z;
         }
+    }
+    return r;
+}
+
+// Two heads of head_dim 128 in one pass: lanes [0,32) hold one head, lanes [32,64) another
+// (l = lane & 31 is the float4 slice in both).  bfly32 inside a half adds exactly what bfly64
+// adds for a head that sits in the lower half with zeros above it, so each half gets the
+// result headnorm_rope_vals would give it.
+template <int HD>
+__device__ __forceinline__ float4 headnorm_rope_halves(float4 v, float4 g, float4 ca, float4 cb, int l) {
+    static_assert(HD == 128, "two heads per wave need 32 lanes per head");
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    c0 = c0 + v.x * v.x;
+    c1 = c1 + v.y * v.y;
+    c2 = c2 + v.z * v.z;
+    c3 = c3 + v.w * v.w;
+    const float ss = bfly32((c0 + c1) + (c2 + c3));
+    const float s = 1.0f / sqrtf(ss / (float)HD + 1e-6f);
+    float4 y;
+    y.x = g.x * (s * v.x);
+    y.y = g.y * (s * v.y);
+    y.z = g.z * (s * v.z);
+    y.w = g.w * (s * v.w);
+    float4 o;
+    o.x = lane_xor_f<16>(y.x);
+    o.y = lane_xor_f<16>(y.y);
+    o.z = lane_xor_f<16>(y.z);
+    o.w = lane_xor_f<16>(y.w);
+    float4 r;
+    if (l < 16) {          // own = real, other = imag: real*cos - imag*sin
+        r.x = y.x * ca.x - o.x * ca.y;
+        r.y = y.y * ca.z - o.y * ca.w;
+        r.z = y.z * cb.x - o.z * cb.y;
+        r.w = y.w * cb.z - o.w * cb.w;
+    } else {               // own = imag, other = real: real*sin + imag*cos
+        r.x = o.x * ca.y + y.x * ca.x;
+        r.y = o.y * ca.w + y.y * ca.z;
+        r.z = o.z * cb.y + y.z * cb.x;
+        r.w = o.w * cb.w + y.w * cb.z;
     }
     return r;
 }

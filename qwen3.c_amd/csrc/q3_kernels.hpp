@@ -55,11 +55,18 @@ struct Attn {
     unsigned long long* stamps;  // diagnostic builds only: s_memrealtime/s_memtime marks of workgroup (0,0)
     int prepared;        // op-level test hook only: q and the k/v of `pos` are already normed + rotated
 };
-// `chunk_slots` workgroups per kv head walk the 64-position chunks of [0,pos].  With
-// multi=false the caller guarantees pos < 64 (one chunk, finalised directly); otherwise each
-// workgroup publishes its chunk partials and the one that draws the last ticket of its kv head
-// merges them -- inside the same launch.
-void attn(const Attn& a, int chunk_slots, bool multi, hipStream_t st);
+// `chunk_slots` workgroups per kv head walk the 64-position chunks of [0,pos].  Three launch
+// shapes, chosen by the position (the graph of a step is built once per shape):
+//   ATT_SINGLE  pos < 64: one chunk, finalised directly (chunk_slots = 1)
+//   ATT_MERGE   each workgroup publishes its chunk partials and the one that draws the last
+//               ticket of its kv head merges them -- inside the same launch
+//   ATT_LONG    pos >= Q3_ATT_LONG: the partials are merged by a second, wide launch (one wave
+//               per 64 output values); a single last arriver would have to pull every
+//               partial of its kv head (135 KB at 4096 positions) through one CU
+enum AttMode { ATT_SINGLE = 0, ATT_MERGE = 1, ATT_LONG = 2 };
+#define Q3_ATT_LONG 1024
+inline AttMode attn_mode(int pos) { return pos < 64 ? ATT_SINGLE : (pos < Q3_ATT_LONG ? ATT_MERGE : ATT_LONG); }
+void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st);
 
 void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, hipStream_t st);
 // first kernel of a step: x = embedding row of ctl->token (eq may be null on later pipeline

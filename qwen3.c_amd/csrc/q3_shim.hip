@@ -106,11 +106,11 @@ struct Dev {
     int max_chunks = 1, chunk_slots = 1;
     bool logits_pinned = false;
     bool use_graph = true;
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] pos < 64, [1] chunked attention
+    hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};   // one per attention launch shape (q3k::AttMode)
     // pipeline / on-device loop: one KV cache per concurrent token stream
     int n_streams = 1;
     size_t cache_floats = 0;      // floats of one stream's K (or V) cache of one layer
-    std::vector<hipGraphExec_t> pgexec;   // [stream*2 + multi], step without the ctl upload
+    std::vector<hipGraphExec_t> pgexec;   // [stream*3 + AttMode], step without the ctl upload
     int* ptokens = nullptr;       // last stage: [n_streams][cap] chosen tokens
     // persistent step kernel (q3_mega.hip)
     bool use_mega = false;
@@ -384,7 +384,7 @@ Dev* attach(Model* m) {
     if (d->loopback) {
         for (int i = 0; i < 2; i++) d->outbox[i] = dalloc<float>(d, d->dim + 1);
     }
-    d->pgexec.assign((size_t)d->n_streams * 2, nullptr);
+    d->pgexec.assign((size_t)d->n_streams * 3, nullptr);
     if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 2048); HIPCHK(hipMemset(d->stamps, 0, 2048 * 8)); }
     HIPCHK(hipHostMalloc((void**)&d->ctl_host, sizeof(q3k::Ctl), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&d->amax_host, sizeof(int), hipHostMallocDefault));
@@ -500,7 +500,7 @@ q3k::Attn attn_args(Dev* d, int l, int stream = 0) {
     return a;
 }
 
-void enqueue_layer(Dev* d, int l, bool multi, int stream = 0) {
+void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
     const LayerDev& L = d->layers[l];
     q3k::Gemv g;
     memset(&g, 0, sizeof(g));
@@ -518,7 +518,7 @@ void enqueue_layer(Dev* d, int l, bool multi, int stream = 0) {
         q3k::Attn a = attn_args(d, l, stream);
         {
             Timed t(d, "attn", 0.0);
-            q3k::attn(a, multi ? d->chunk_slots : 1, multi, d->st);
+            q3k::attn(a, d->chunk_slots, mode, d->st);
         }
     }
     {   // Wo + residual (forward.c:292-298)
@@ -562,7 +562,7 @@ void enqueue_head(Dev* d) {
 }
 
 // everything of one step that runs on this device, between the ctl upload and the logits
-void enqueue_step(Dev* d, bool multi, int stream = 0) {
+void enqueue_step(Dev* d, q3k::AttMode mode, int stream = 0) {
     if (d->use_mega && !d->prof && !d->tap) {
         q3k::step(d->mega_dev[stream], d->mega_host[stream], d->st);
         HIPCHK(hipMemcpyAsync(d->merr_host, &d->msync->error, sizeof(unsigned), hipMemcpyDeviceToHost, d->st));
@@ -573,7 +573,7 @@ void enqueue_step(Dev* d, bool multi, int stream = 0) {
         q3k::begin_step(d->ctl, d->has_embed ? d->emb_q : nullptr, d->emb_s, d->dim, d->x, d->rope, d->hd,
                         d->cs_cur, d->st);
     }
-    for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, multi, stream);
+    for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, mode, stream);
     if (d->has_cls) enqueue_head(d);
 }
 
@@ -581,11 +581,11 @@ void fetch_logits_async(Dev* d) {
     HIPCHK(hipMemcpyAsync(d->m->state.logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost, d->st));
 }
 
-hipGraphExec_t build_graph(Dev* d, bool multi, bool with_logits) {
+hipGraphExec_t build_graph(Dev* d, q3k::AttMode mode, bool with_logits) {
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(d->st, hipStreamCaptureModeThreadLocal));
     HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
-    enqueue_step(d, multi);
+    enqueue_step(d, mode);
     if (with_logits) fetch_logits_async(d);
     HIPCHK(hipStreamEndCapture(d->st, &graph));
     hipGraphExec_t exec = nullptr;
@@ -604,13 +604,13 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
     check_step_args(d, token, pos);
     HIPCHK(hipSetDevice(d->device));
     if (d->world > 1) Q3_DIE("this Model is one stage of a %d-stage pipeline: use q3_pipeline_run()", d->world);
-    const bool multi = pos >= Q3_ATT_CHUNK;
+    const q3k::AttMode mode = q3k::attn_mode(pos);
     d->ctl_host->token = token;
     d->ctl_host->pos = pos;
     const bool pinned_ok = d->logits_pinned;
     if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
-        hipGraphExec_t& ex = d->gexec[multi ? 1 : 0];
-        if (!ex) ex = build_graph(d, multi, true);
+        hipGraphExec_t& ex = d->gexec[(int)mode];
+        if (!ex) ex = build_graph(d, mode, true);
         HIPCHK(hipGraphLaunch(ex, d->st));
         if (to_host) {
             HIPCHK(hipStreamSynchronize(d->st));
@@ -620,7 +620,7 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
     }
     prof_begin(d);
     HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
-    enqueue_step(d, multi);
+    enqueue_step(d, mode);
     if (d->tap) {
         HIPCHK(hipMemcpyAsync(d->tap_host.data(), d->tap_dev, d->tap_host.size() * 4, hipMemcpyDeviceToHost, d->st));
     }
@@ -844,21 +844,21 @@ void ensure_token_log(Dev* d, int per_stream) {
 
 __global__ void k_log_token(const int* tok, int* log_slot) { *log_slot = *tok; }
 
-void launch_stage(Dev* d, bool multi, int stream) {
+void launch_stage(Dev* d, q3k::AttMode mode, int stream) {
     const bool pinned_ok = true;
     if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
-        hipGraphExec_t& ex = d->pgexec[(size_t)stream * 2 + (multi ? 1 : 0)];
+        hipGraphExec_t& ex = d->pgexec[(size_t)stream * 3 + (int)mode];
         if (!ex) {
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(d->st, hipStreamCaptureModeThreadLocal));
-            enqueue_step(d, multi, stream);
+            enqueue_step(d, mode, stream);
             HIPCHK(hipStreamEndCapture(d->st, &graph));
             HIPCHK(hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0));
             HIPCHK(hipGraphDestroy(graph));
         }
         HIPCHK(hipGraphLaunch(ex, d->st));
     } else {
-        enqueue_step(d, multi, stream);
+        enqueue_step(d, mode, stream);
     }
 }
 
@@ -900,7 +900,7 @@ void pipeline_tick(Dev* d, int first_token, int pos0, int s, int k) {
     int* tok_slot_out = reinterpret_cast<int*>(d->xout + d->dim);
     HIPCHK(hipSetDevice(d->device));
     q3k::set_ctl(d->ctl, (r == 0 && k > 0) ? tok_slot_in : nullptr, r == 0 ? first_token : 0, pos, d->st);
-    launch_stage(d, pos >= Q3_ATT_CHUNK, s);
+    launch_stage(d, q3k::attn_mode(pos), s);
     if (!last) {
         HIPCHK(hipMemcpyAsync(d->xout, d->x, (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
     } else {
@@ -996,7 +996,7 @@ void q3_layer_step(Model* m, int layer, int pos, const float* x_in, float* x_out
     HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
     q3k::begin_step(d->ctl, nullptr, nullptr, d->dim, d->x, d->rope, d->hd, d->cs_cur, d->st);
     HIPCHK(hipMemcpyAsync(d->x, x_in, (size_t)d->dim * 4, hipMemcpyHostToDevice, d->st));
-    enqueue_layer(d, layer, pos >= Q3_ATT_CHUNK);
+    enqueue_layer(d, layer, q3k::attn_mode(pos));
     HIPCHK(hipStreamSynchronize(d->st));
     HIPCHK(hipMemcpy(x_out, d->x, (size_t)d->dim * 4, hipMemcpyDeviceToHost));
     prof_collect(d);
@@ -1101,8 +1101,7 @@ void attention(Model* m, int layer, int pos) {
     q3k::begin_step(d->ctl, nullptr, nullptr, d->dim, d->x, d->rope, d->hd, d->cs_cur, d->st);
     q3k::Attn a = attn_args(d, layer);
     a.of = d->att_f;
-    const bool multi = pos >= Q3_ATT_CHUNK;
-    q3k::attn(a, multi ? d->chunk_slots : 1, multi, d->st);
+    q3k::attn(a, d->chunk_slots, q3k::attn_mode(pos), d->st);
     HIPCHK(hipStreamSynchronize(d->st));
     if (m->state.x_rms_norm) {
         HIPCHK(hipMemcpy(m->state.x_rms_norm, d->att_f, (size_t)d->P * 4, hipMemcpyDeviceToHost));
@@ -1198,8 +1197,7 @@ void q3_op_attention(const float* q, const float* kcache, const float* vcache, i
     a.oq = doq.as<int8_t>(); a.os = dos.as<float>(); a.of = dof.as<float>(); a.qdbg = nullptr;
     a.n_heads = n_heads; a.n_kv = n_kv_heads; a.hd = hd; a.seq_len = seq; a.max_chunks = max_chunks;
     a.prepared = 1;
-    const bool multi = T > Q3_ATT_CHUNK;
-    q3k::attn(a, multi ? max_chunks : 1, multi, st);
+    q3k::attn(a, max_chunks, q3k::attn_mode(T - 1), st);
     dof.to_host(out, st);
 }
 

@@ -116,7 +116,7 @@ def test_headnorm_rope(hip, orc, hd, pos):
     assert np.array_equal(one, exp1)
 
 
-@pytest.mark.parametrize("T", [1, 2, 7, 63, 64, 65, 128, 130, 200, 1000])
+@pytest.mark.parametrize("T", [1, 2, 7, 63, 64, 65, 128, 130, 200, 1000, 1024, 1025, 2100, 4200])
 @pytest.mark.parametrize("heads", [(4, 1, 128), (2, 1, 64), (8, 2, 128), (16, 8, 128)])
 def test_attention(hip, orc, T, heads):
     H, KV, hd = heads
@@ -134,7 +134,9 @@ def test_attention(hip, orc, T, heads):
     orc.orc_set_mode(Q.ORC_REF)
     orc.orc_attention_raw(Q.fptr(q), Q.fptr(k), Q.fptr(v), T, H, KV, hd, Q.fptr(ref))
     assert np.array_equal(got, tree)
-    assert rel_err(got, ref) <= 2e-6
+    # tree order vs the reference's sequential order: the gap is the reference's own summation noise,
+    # which grows with the number of cached positions
+    assert rel_err(got, ref) <= max(2e-6, 2e-9 * T)
 
 
 def test_swiglu_expf_softmax_scalars(hip, orc):
