@@ -258,12 +258,12 @@ def main():
             ach = round(hip.q3_gemv_bytes(2 * p.hidden_dim, p.dim) / us_best / 1e3, 1)
             traffic = None
             try:   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["gateup"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")))["kernels"]["gateup"]
                 if args.model == "4B":
                     traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
             except Exception:
                 pass
-            out["roofline"] = {"bound": "hbm", "kernel": "k_gemv2<PRO_NORM,EPI_SWIGLU> (gate/up GEMV)",
+            out["roofline"] = {"bound": "hbm", "kernel": "k_gemv3<PRO_NORM,EPI_SWIGLU,3,8> (gate/up GEMV)",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "timing": "in-kernel device clock (s_memrealtime, first workgroup in .. last out) of the "
