@@ -98,6 +98,17 @@ int q3_device_argmax(Model* m);           /* argmax of the device logits */
  * copied to the host only after the last step. */
 int q3_generate_greedy(Model* m, int token, int pos, int n, int* out_tokens);
 
+/* Device-side sampling (no counterpart call in the reference; same result as its host
+ * sample(), src/sampler.c:189-201, applied to these logits: temperature, softmax, top-p
+ * nucleus, one xorshift64* draw, src/xorshift.c:7-16).  `temperature` and `top_p` are
+ * clamped as sampler_create() does (src/sampler.c:33-52).  The logits the last step left on
+ * the device are overwritten with the probabilities, as sample() does to its argument;
+ * *seed advances by one draw.  Returns the token. */
+int q3_device_sample(Model* m, float temperature, float top_p, uint64_t* seed);
+/* q3_generate_greedy() with that sampler in place of the argmax; the RNG state comes back in *seed. */
+int q3_generate_sampled(Model* m, int token, int pos, int n, float temperature, float top_p, uint64_t* seed,
+                        int* out_tokens);
+
 /* Fill positions [0, T) of every layer's device KV cache with finite
  * pseudo-random values (timing of long contexts without T real steps). */
 void q3_kv_fill_random(Model* m, int T, uint64_t seed);
@@ -126,6 +137,9 @@ void q3_op_attention(const float* q, const float* kcache, const float* vcache, i
                      int n_heads, int n_kv_heads, int head_dim, float* out);
 void q3_op_swiglu(const float* gate, const float* up, int n, float* out);
 void q3_op_expf(const float* x, int n, float* out);
+/* reference sample() (src/sampler.c:189-201) on host logits through the device sampler: returns the
+ * token, leaves the probabilities in `logits`, advances *seed by one draw. */
+int q3_op_sample(float* logits, int n, float temperature, float top_p, uint64_t* seed);
 
 /* ---- timing ----------------------------------------------------------- */
 typedef struct Q3ProfEntry {

@@ -139,7 +139,15 @@ void orc_softmax(float* x, int size) {
     }
     if (g_mode == ORC_TREE) {
         for (int i = 0; i < size; i++) x[i] = q3_expf(x[i] - max_val);
-        const float sum = sum256(x, size);
+        float sum;
+        if (size <= Q3_SM_CHUNK) {
+            sum = sum256(x, size);
+        } else {            /* one partial per chunk, added in chunk order (q3_numerics.h "softmax") */
+            sum = 0.0f;
+            for (int c0 = 0; c0 < size; c0 += Q3_SM_CHUNK) {
+                sum = sum + sum256(x + c0, size - c0 < Q3_SM_CHUNK ? size - c0 : Q3_SM_CHUNK);
+            }
+        }
         for (int i = 0; i < size; i++) x[i] /= sum;
         return;
     }
@@ -437,4 +445,85 @@ void orc_layer_step(Model* m, int layer, int pos, const float* x_in, float* x_ou
     orc_matmul(s->x_rms_norm, &s->qh, w->w2 + l, p->hidden_dim, dim, bs);
     for (int i = 0; i < dim; i++) s->x[i] += s->x_rms_norm[i];
     memcpy(x_out, s->x, (size_t)dim * sizeof(float));
+}
+
+/* ---------------------------------------------------------- sampler ---- */
+/* the device-side sampler is checked against this restatement of the
+ * reference's sample() (src/sampler.c:189-201) and its helpers.  In ORC_REF mode it is the
+ * reference bit for bit (pinned against oracle/_ref by tests/test_oracle.py); in ORC_TREE mode
+ * only the softmax changes (tree sum, q3_expf), which is what the kernels compute. */
+
+/* reference src/xorshift.c:7-16 */
+uint32_t orc_xorshift_int32(uint64_t* state) {
+    *state ^= *state >> 12;
+    *state ^= *state << 25;
+    *state ^= *state >> 27;
+    return (uint32_t)((*state * 0x2545F4914F6CDD1Dull) >> 32);
+}
+float orc_xorshift_float(uint64_t* state) { return (orc_xorshift_int32(state) >> 8) / 16777216.0f; }
+
+/* the clamps of sampler_create() (src/sampler.c:33-52) */
+void orc_sampler_clamp(float* temperature, float* top_p) {
+    const float epsilon = 1e-6f;
+    if (*top_p > 1.0f || isnan(*top_p) || 1 == isinf(*top_p)) *top_p = 1.0f;
+    else if (*top_p < epsilon || -1 == isinf(*top_p)) *top_p = epsilon;
+    if (isnan(*temperature) || 1 == isinf(*temperature)) *temperature = 1.0f;
+    else if (*temperature < epsilon || -1 == isinf(*temperature)) *temperature = epsilon;
+}
+
+typedef struct { float sample; int index; } OrcProb;
+/* descending by probability; equal probabilities keep their index order -- what the reference's
+ * qsort (a stable merge sort in the glibc of this image) produces with its comparator
+ * (src/sampler.c:138-148) */
+static int cmp_prob(const void* a, const void* b) {
+    const OrcProb* n = (const OrcProb*)a;
+    const OrcProb* m = (const OrcProb*)b;
+    if (n->sample > m->sample) return -1;
+    if (n->sample < m->sample) return 1;
+    return (n->index > m->index) - (n->index < m->index);
+}
+
+/* sample() with the Sampler fields passed explicitly; `logits` is modified in place exactly
+ * as the reference does (scaled, then softmaxed); *seed advances by one draw */
+int orc_sample(float* logits, int vocab_size, float temperature, float top_p, uint64_t* seed) {
+    for (int q = 0; q < vocab_size; q++) logits[q] /= temperature;        /* sampler.c:191-193 */
+    orc_softmax(logits, vocab_size);                                       /* :196 */
+    const float coin = orc_xorshift_float(seed);                           /* :198 */
+    OrcProb* dist = (OrcProb*)malloc((size_t)vocab_size * sizeof(OrcProb));
+    for (int i = 0; i < vocab_size; i++) {                                 /* :167-170 */
+        dist[i].index = i;
+        dist[i].sample = logits[i];
+    }
+    qsort(dist, (size_t)vocab_size, sizeof(OrcProb), cmp_prob);            /* :173 */
+    float mass = 0.0f;                                                     /* sampler_mass_index, :88-113 */
+    int id = vocab_size - 1;
+    for (int i = 0; i < vocab_size; i++) {
+        mass += dist[i].sample;
+        if (mass > top_p) {
+            id = i;
+            break;
+        }
+    }
+    if (mass < 1e-3f) {
+        for (int i = 0; i <= id; i++) mass += dist[i].sample;
+    }
+    float cdf = 0.0f;                                                      /* sampler_cdf_index, :126-136 */
+    const float r = coin * mass;
+    int tok = dist[id > 0 ? id - 1 : 0].index;                             /* the reference's fallback dist[n-1] */
+    int found = 0;
+    for (int i = 0; i <= id; i++) {
+        cdf += dist[i].sample;
+        if (r < cdf) {
+            tok = dist[i].index;
+            found = 1;
+            break;
+        }
+    }
+    /* n = 0 and no hit (only after the healing above doubled the mass, coin > 0.5): the
+     * reference returns dist[-1].index, an out-of-bounds read of the allocator's size word in
+     * front of its calloc'd array, whose upper half is 0 with glibc -- token 0 is what the
+     * reference build returns, so that is what is restated */
+    if (!found && id == 0) tok = 0;
+    free(dist);
+    return tok;
 }

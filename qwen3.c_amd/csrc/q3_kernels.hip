@@ -273,10 +273,24 @@ void rmsnorm(float* out, const float* x, const float* w, int n, hipStream_t st) 
     hipLaunchKernelGGL(k_rmsnorm, dim3(1), dim3(64), 0, st, out, x, w, n);
 }
 
-// softmax over an arbitrary length (reference forward.c:34-77): max, q3_expf, SUM256, divide
+// SUM256 of n floats (any n >= 1) by ONE wave: lane l, component k walks x[256 b + 4 l + k]
+__device__ __forceinline__ float sum256_wave(const float* x, int n, int lane) {
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    for (int i = 4 * lane; i < n; i += 256) {
+        c0 = c0 + x[i];
+        if (i + 1 < n) c1 = c1 + x[i + 1];
+        if (i + 2 < n) c2 = c2 + x[i + 2];
+        if (i + 3 < n) c3 = c3 + x[i + 3];
+    }
+    return bfly64((c0 + c1) + (c2 + c3));
+}
+
+// softmax over an arbitrary length (reference forward.c:34-77; tree: q3_numerics.h "softmax"):
+// max, q3_expf, chunk sums by the 16 waves, sequential sum of the chunk sums, divide.  One workgroup
+// (the exported softmax() is a host-pointer convenience; the sampler has its own multi-workgroup form).
 __global__ __launch_bounds__(1024) void k_softmax(float* x, int n) {
     __shared__ float red[16];
-    __shared__ float bc;
+    __shared__ float ps[1024];          // chunk sums: n <= 4 Mi elements
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     float m = -3.4e38f;
     for (int i = tid; i < n; i += 1024) m = fmaxf(m, x[i]);
@@ -286,20 +300,20 @@ __global__ __launch_bounds__(1024) void k_softmax(float* x, int n) {
     m = red[0];
     for (int w = 1; w < 16; w++) m = fmaxf(m, red[w]);
     for (int i = tid; i < n; i += 1024) x[i] = q3_expf(x[i] - m);
+    __threadfence_block();
     __syncthreads();
-    if (wave == 0) {
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-        for (int i = 4 * lane; i < n; i += 256) {
-            c0 = c0 + x[i];
-            if (i + 1 < n) c1 = c1 + x[i + 1];
-            if (i + 2 < n) c2 = c2 + x[i + 2];
-            if (i + 3 < n) c3 = c3 + x[i + 3];
-        }
-        const float sum = bfly64((c0 + c1) + (c2 + c3));
-        if (lane == 0) bc = sum;
+    const int nchunks = (n + Q3_SM_CHUNK - 1) / Q3_SM_CHUNK;
+    for (int c = wave; c < nchunks; c += 16) {
+        const int c0 = c * Q3_SM_CHUNK;
+        const float s = sum256_wave(x + c0, n - c0 < Q3_SM_CHUNK ? n - c0 : Q3_SM_CHUNK, lane);
+        if (lane == 0) ps[c] = s;
     }
     __syncthreads();
-    const float sum = bc;
+    float sum = ps[0];
+    if (nchunks > 1) {
+        sum = 0.0f;
+        for (int c = 0; c < nchunks; c++) sum = sum + ps[c];
+    }
     for (int i = tid; i < n; i += 1024) x[i] = x[i] / sum;
 }
 void softmax(float* x, int n, hipStream_t st) {

@@ -90,6 +90,26 @@ void swiglu(const float* g, const float* u, int n, float* out, hipStream_t st);
 void expf_map(const float* x, int n, float* out, hipStream_t st);
 void fill_random(float* p, size_t n, uint64_t seed, hipStream_t st);
 
+// ---- device-side sampling (q3_sample.hip) -----------------------------------------------
+#define Q3_SAMPLE_MAX_CHUNKS 1024
+struct SampleBufs {
+    float* pmax;      // [Q3_SAMPLE_MAX_CHUNKS]
+    float* psum;      // [Q3_SAMPLE_MAX_CHUNKS]
+    int* idx_in;      // [n] 0..n-1 (sample_init)
+    float* key_out;   // [n] sorted probabilities
+    int* idx_out;     // [n] their token ids
+    void* tmp;        // radix-sort scratch, sample_temp_bytes(n)
+    size_t tmp_bytes;
+};
+size_t sample_temp_bytes(int n);
+void sample_init(const SampleBufs& b, int n, hipStream_t st);
+// reference sample() (src/sampler.c:189-201) on the device.  `logits` is overwritten with the
+// probabilities, as the reference does.  The coin is `coin` (drawn by the caller) unless
+// `seed_dev` is given: then the kernel draws it from that xorshift64* state and advances it.
+// The token goes to *out (and *out2 when non-null).
+void sample(float* logits, int n, float temperature, float top_p, float coin, unsigned long long* seed_dev,
+            const SampleBufs& b, int* out, int* out2, hipStream_t st);
+
 
 // ---- persistent step kernel (q3_mega.hip) --------------------------------------------
 struct MegaSync {                        // device memory, zeroed once at attach

@@ -38,6 +38,12 @@
  *                 L = sum_c w_c*l_c ; A[j] = sum_c w_c*O_c[j] (ascending c)
  *                 out[j] = A[j]/L                                    [src/forward.c:141-195]
  *   swiglu        (x1 * (1.0f/(1.0f+q3_expf(-x1)))) * x3             [src/forward.c:122-139]
+ *   softmax       m = max x_i ; e_i = q3_expf(x_i - m) ;
+ *                 sum = SUM256(e) when size <= Q3_SM_CHUNK, else the sums SUM256(e[c]) of the
+ *                 consecutive Q3_SM_CHUNK-element chunks added in ascending order of c (one
+ *                 workgroup per chunk on the device) ; out_i = e_i/sum   [src/forward.c:34-77]
+ *   sample        logits/temperature (true division), softmax as above, then the reference's own
+ *                 sequential arithmetic on the stably sorted distribution (src/sampler.c:88-136)
  *   residual add, embedding dequant (q*s): single rounded ops, exact.
  *
  * No fused multiply-add is ever formed implicitly: device code is built with
@@ -58,6 +64,7 @@
 #define Q3_ATT_CHUNK 64      /* cache positions per attention chunk          */
 #define Q3_ATT_STREAMS 2     /* interleaved accumulation streams per chunk   */
 #define Q3_MM_COLS 16        /* column partials of the matmul group sum      */
+#define Q3_SM_CHUNK 4096     /* elements per partial sum of a long softmax   */
 
 Q3_HD float q3_bits_to_float(uint32_t u) {
     union { uint32_t u; float f; } c; c.u = u; return c.f;

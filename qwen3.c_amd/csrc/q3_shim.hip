@@ -112,6 +112,14 @@ struct Dev {
     size_t cache_floats = 0;      // floats of one stream's K (or V) cache of one layer
     std::vector<hipGraphExec_t> pgexec;   // [stream*3 + AttMode], step without the ctl upload
     int* ptokens = nullptr;       // last stage: [n_streams][cap] chosen tokens
+    // device-side sampling (q3_sample.hip)
+    q3k::SampleBufs sb = {};
+    bool sb_ready = false;
+    bool samp_on = false;         // the generation loop samples instead of taking the argmax
+    float samp_t = 1.0f, samp_p = 1.0f;
+    unsigned long long* seed_dev = nullptr;
+    int* samp_tok = nullptr;      // device slot + pinned host copy of the sampled token
+    int* samp_tok_host = nullptr;
     // persistent step kernel (q3_mega.hip)
     bool use_mega = false;
     q3k::MegaSync* msync = nullptr;
@@ -906,7 +914,8 @@ void pipeline_tick(Dev* d, int first_token, int pos0, int s, int k) {
     } else {
         // greedy pick on the device; with one stage it feeds the next step directly
         int* dst = N == 1 ? tok_slot_in : tok_slot_out;
-        q3k::argmax(d->logits, d->V, d->amax_scratch, dst, nullptr, d->st);
+        if (d->samp_on) q3k::sample(d->logits, d->V, d->samp_t, d->samp_p, 0.0f, d->seed_dev, d->sb, dst, nullptr, d->st);
+        else q3k::argmax(d->logits, d->V, d->amax_scratch, dst, nullptr, d->st);
         hipLaunchKernelGGL(k_log_token, dim3(1), dim3(1), 0, d->st, dst, d->ptokens + (size_t)s * d->ptokens_cap + k);
     }
 }
@@ -961,6 +970,80 @@ int q3_generate_greedy(Model* m, int token, int pos, int n, int* out_tokens) {
     pipeline_run(d, token, pos, n);
     if (out_tokens) q3_pipeline_tokens(m, 0, out_tokens, n);
     q3_logits_fetch(m);
+    return n;
+}
+
+// ---- device-side sampling ---------------------------------------------
+namespace {
+void ensure_sampler(Dev* d) {
+    if (d->sb_ready) return;
+    d->sb.pmax = dalloc<float>(d, Q3_SAMPLE_MAX_CHUNKS);
+    d->sb.psum = dalloc<float>(d, Q3_SAMPLE_MAX_CHUNKS);
+    d->sb.idx_in = dalloc<int>(d, d->V);
+    d->sb.key_out = dalloc<float>(d, d->V);
+    d->sb.idx_out = dalloc<int>(d, d->V);
+    d->sb.tmp_bytes = q3k::sample_temp_bytes(d->V);
+    d->sb.tmp = dalloc<char>(d, d->sb.tmp_bytes ? d->sb.tmp_bytes : 16);
+    d->seed_dev = dalloc<unsigned long long>(d, 1);
+    d->samp_tok = dalloc<int>(d, 1);
+    HIPCHK(hipHostMalloc((void**)&d->samp_tok_host, sizeof(int), hipHostMallocDefault));
+    q3k::sample_init(d->sb, d->V, d->st);
+    d->sb_ready = true;
+}
+// the clamps of the reference's sampler_create() (src/sampler.c:33-52)
+void clamp_sampler(float& temperature, float& top_p) {
+    const float epsilon = 1e-6f;
+    if (top_p > 1.0f || std::isnan(top_p) || (std::isinf(top_p) && top_p > 0)) top_p = 1.0f;
+    else if (top_p < epsilon) top_p = epsilon;
+    if (std::isnan(temperature) || (std::isinf(temperature) && temperature > 0)) temperature = 1.0f;
+    else if (temperature < epsilon) temperature = epsilon;
+}
+// reference src/xorshift.c:7-16
+float host_xorshift_float(uint64_t* state) {
+    *state ^= *state >> 12;
+    *state ^= *state << 25;
+    *state ^= *state >> 27;
+    const uint32_t r = (uint32_t)((*state * 0x2545F4914F6CDD1Dull) >> 32);
+    return (float)(r >> 8) / 16777216.0f;
+}
+}  // namespace
+
+/* reference sample() (src/sampler.c:189-201) on the logits the last step left on the device
+ * (q3_forward_device / forward): temperature, softmax, top-p, one xorshift64* draw from *seed.
+ * The device logits are overwritten with the probabilities, as sample() does to its argument. */
+int q3_device_sample(Model* m, float temperature, float top_p, uint64_t* seed) {
+    Dev* d = attach(m);
+    if (!d->has_cls) Q3_DIE("q3_device_sample: this pipeline stage holds no logits");
+    if (!seed) Q3_DIE("q3_device_sample: seed is NULL");
+    ensure_sampler(d);
+    clamp_sampler(temperature, top_p);
+    const float coin = host_xorshift_float(seed);
+    q3k::sample(d->logits, d->V, temperature, top_p, coin, nullptr, d->sb, d->samp_tok, nullptr, d->st);
+    HIPCHK(hipMemcpyAsync(d->samp_tok_host, d->samp_tok, sizeof(int), hipMemcpyDeviceToHost, d->st));
+    HIPCHK(hipStreamSynchronize(d->st));
+    return *d->samp_tok_host;
+}
+
+/* q3_generate_greedy with the sampler in place of the argmax: no host round trip per token, the
+ * RNG state travels to the device and comes back in *seed. */
+int q3_generate_sampled(Model* m, int token, int pos, int n, float temperature, float top_p, uint64_t* seed,
+                        int* out_tokens) {
+    Dev* d = attach(m);
+    if (d->world > 1) Q3_DIE("q3_generate_sampled: single-GPU models only");
+    if (!seed) Q3_DIE("q3_generate_sampled: seed is NULL");
+    if (pos + n > d->seq) n = d->seq - pos;
+    if (n <= 0) return 0;
+    ensure_sampler(d);
+    clamp_sampler(temperature, top_p);
+    unsigned long long s = *seed;
+    HIPCHK(hipMemcpyAsync(d->seed_dev, &s, sizeof(s), hipMemcpyHostToDevice, d->st));
+    HIPCHK(hipStreamSynchronize(d->st));
+    d->samp_on = true; d->samp_t = temperature; d->samp_p = top_p;
+    pipeline_run(d, token, pos, n);
+    d->samp_on = false;
+    if (out_tokens) q3_pipeline_tokens(m, 0, out_tokens, n);
+    HIPCHK(hipMemcpy(&s, d->seed_dev, sizeof(s), hipMemcpyDeviceToHost));
+    *seed = s;
     return n;
 }
 
@@ -1206,6 +1289,29 @@ void q3_op_swiglu(const float* gate, const float* up, int n, float* out) {
     DBuf dg(gate, (size_t)n * 4), du(up, (size_t)n * 4), dout((size_t)n * 4);
     q3k::swiglu(dg.as<float>(), du.as<float>(), n, dout.as<float>(), st);
     dout.to_host(out, st);
+}
+
+// sample() on host logits: returns the token, leaves the probabilities in `logits` (as the
+// reference does) and advances *seed by one draw
+int q3_op_sample(float* logits, int n, float temperature, float top_p, uint64_t* seed) {
+    hipStream_t st = ops_stream();
+    if (n < 1 || !seed) Q3_DIE("q3_op_sample: bad arguments");
+    clamp_sampler(temperature, top_p);
+    DBuf dl(logits, (size_t)n * 4), dmax((size_t)Q3_SAMPLE_MAX_CHUNKS * 4), dsum((size_t)Q3_SAMPLE_MAX_CHUNKS * 4);
+    DBuf didx((size_t)n * 4), dkey((size_t)n * 4), dido((size_t)n * 4), dtok(sizeof(int));
+    q3k::SampleBufs b;
+    b.pmax = dmax.as<float>(); b.psum = dsum.as<float>(); b.idx_in = didx.as<int>();
+    b.key_out = dkey.as<float>(); b.idx_out = dido.as<int>();
+    b.tmp_bytes = q3k::sample_temp_bytes(n);
+    DBuf dtmp(b.tmp_bytes ? b.tmp_bytes : 16);
+    b.tmp = dtmp.p;
+    q3k::sample_init(b, n, st);
+    const float coin = host_xorshift_float(seed);
+    q3k::sample(dl.as<float>(), n, temperature, top_p, coin, nullptr, b, dtok.as<int>(), nullptr, st);
+    int tok = -1;
+    dl.to_host(logits, st);
+    dtok.to_host(&tok, st);
+    return tok;
 }
 
 void q3_op_expf(const float* x, int n, float* out) {

@@ -221,6 +221,12 @@ def hip_lib():
         lib.q3_pipeline_selftest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         lib.q3_pipeline_allreduce_max.restype = C.c_double
         lib.q3_pipeline_allreduce_max.argtypes = [C.c_double]
+        lib.q3_op_sample.restype = C.c_int
+        lib.q3_op_sample.argtypes = [c_float_p, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64)]
+        lib.q3_device_sample.restype = C.c_int
+        lib.q3_device_sample.argtypes = [ModelP, C.c_float, C.c_float, C.POINTER(C.c_uint64)]
+        lib.q3_generate_sampled.restype = C.c_int
+        lib.q3_generate_sampled.argtypes = [ModelP, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         lib.q3_debug_gemv_loop.restype = C.c_double
         lib.q3_debug_gemv_loop.argtypes = [ModelP, C.c_char_p, C.c_int, C.c_int, C.c_int]
         lib.q3_debug_stamps.restype = C.c_int
@@ -262,8 +268,19 @@ def oracle_lib():
         lib.orc_forward.restype = c_float_p
         lib.orc_forward.argtypes = [ModelP, C.c_int, C.c_int]
         lib.orc_layer_step.argtypes = [ModelP, C.c_int, C.c_int, c_float_p, c_float_p]
+        lib.orc_xorshift_float.restype = C.c_float
+        lib.orc_xorshift_float.argtypes = [C.POINTER(C.c_uint64)]
+        lib.orc_sampler_clamp.argtypes = [c_float_p, c_float_p]
+        lib.orc_sample.restype = C.c_int
+        lib.orc_sample.argtypes = [c_float_p, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64)]
         _cache["orc"] = lib
     return _cache["orc"]
+
+
+class RefSampler(C.Structure):
+    """reference include/sampler.h:21-27"""
+    _fields_ = [("dist", C.c_void_p), ("seed", C.c_uint64), ("temperature", C.c_float), ("top_p", C.c_float),
+                ("vocab_size", C.c_int)]
 
 
 def reference_lib(fast=False):
@@ -292,6 +309,11 @@ def reference_lib(fast=False):
         lib.swiglu.argtypes = [c_float_p, c_float_p, C.c_int]
         lib.attention.argtypes = [ModelP, C.c_int, C.c_int]
         lib.q8_quantize.argtypes = [Q8P, c_float_p, C.c_int, C.c_int]
+        lib.sampler_create.restype = C.POINTER(RefSampler)
+        lib.sampler_create.argtypes = [C.c_int, C.c_float, C.c_float, C.c_uint64]
+        lib.sampler_free.argtypes = [C.POINTER(RefSampler)]
+        lib.sample.restype = C.c_int
+        lib.sample.argtypes = [C.POINTER(RefSampler), c_float_p]
         _cache[key] = lib
     return _cache[key]
 

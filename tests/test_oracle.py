@@ -149,3 +149,43 @@ def test_oracle_threads_do_not_change_results(host, orc):
         host.q3_model_close(m)
     orc.orc_set_threads(1)
     assert np.array_equal(outs[0], outs[1])
+
+
+def sampler_logits(rng, vocab, kind):
+    """logits of three shapes: peaked (a real model), flat (random-init), with exact ties"""
+    if kind == "peaked":
+        x = rng.standard_normal(vocab).astype(np.float32) * 2.0
+        x[rng.integers(0, vocab, size=5)] += np.float32(9.0)
+    elif kind == "flat":
+        x = (rng.standard_normal(vocab) * 0.05).astype(np.float32)
+    else:
+        x = rng.integers(-3, 4, size=vocab).astype(np.float32)      # many equal probabilities
+    return x
+
+
+@pytest.mark.parametrize("vocab", [512, 5000, 151936])
+def test_sampler_restatement_equals_reference_sample(orc, vocab):
+    """ORC_REF orc_sample() == the reference's sample() (src/sampler.c:189-201): same token, same
+    probabilities left in the logits buffer, same RNG state, over runs of draws."""
+    ref = Q.reference_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref is not built and /root/reference is absent")
+    orc.orc_set_mode(Q.ORC_REF)
+    rng = np.random.default_rng(vocab)
+    for kind in ("peaked", "flat", "ties"):
+        for temperature, top_p in ((1.0, 0.9), (0.7, 0.95), (1.3, 1.0), (0.0, 0.5), (1.0, 0.0)):
+            seed = int(rng.integers(1, 2**63))
+            s = ref.sampler_create(vocab, temperature, top_p, seed)
+            t = np.array([temperature], np.float32); pp = np.array([top_p], np.float32)
+            orc.orc_sampler_clamp(Q.fptr(t), Q.fptr(pp))
+            assert t[0] == s.contents.temperature and pp[0] == s.contents.top_p
+            state = C.c_uint64(seed)
+            for _ in range(3 if vocab > 10000 else 8):
+                x = sampler_logits(rng, vocab, kind)
+                a, b = x.copy(), x.copy()
+                ta = ref.sample(s, Q.fptr(a))
+                tb = orc.orc_sample(Q.fptr(b), vocab, float(t[0]), float(pp[0]), C.byref(state))
+                assert ta == tb
+                assert np.array_equal(a, b, equal_nan=True)
+                assert s.contents.seed == state.value
+            ref.sampler_free(s)
