@@ -113,27 +113,35 @@ __global__ __launch_bounds__(64) void k_nucleus(const float* __restrict__ prob, 
         coin = xorshift_float(&s);
         if (lane == 0) *seed = s;
     }
+    // The walks below add 64 entries per step (one per lane, broadcast with v_readlane) in straight-line
+    // code: the running sum is the only dependency, the "first index where the condition held" is
+    // carried in selects, and there is one branch per 64 entries instead of one per entry.
     // sampler_mass_index (sampler.c:88-113)
     float mass = 0.0f;
     int id = n - 1;
-    bool hit = false;
-    for (int b = 0; b < n && !hit; b += 64) {
-        const float v = (b + lane < n) ? prob[b + lane] : 0.0f;
-        const int cnt = n - b < 64 ? n - b : 64;
-        for (int k = 0; k < cnt; k++) {
-            mass = mass + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
-            if (mass > top_p) {
-                id = b + k;
-                hit = true;
-                break;
-            }
+    for (int b = 0; b < n; b += 64) {
+        const float v = (b + lane < n) ? prob[b + lane] : 0.0f;      // +0 past the end: exact
+        float run = mass, at = 0.0f;
+        int first = 64;
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+            run = run + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+            const bool c = (run > top_p) && (first == 64);
+            first = c ? k : first;
+            at = c ? run : at;
         }
+        if (first < 64) {
+            id = b + first;
+            mass = at;
+            break;
+        }
+        mass = run;
     }
     if (mass < 1e-3f) {                  // "heal the sampled distribution"
         for (int b = 0; b <= id; b += 64) {
             const float v = (b + lane <= id) ? prob[b + lane] : 0.0f;
-            const int cnt = id + 1 - b < 64 ? id + 1 - b : 64;
-            for (int k = 0; k < cnt; k++)
+#pragma unroll
+            for (int k = 0; k < 64; k++)
                 mass = mass + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
         }
     }
@@ -141,15 +149,18 @@ __global__ __launch_bounds__(64) void k_nucleus(const float* __restrict__ prob, 
     const float r = coin * mass;
     float cdf = 0.0f;
     int pick = -1;
-    for (int b = 0; b <= id && pick < 0; b += 64) {
+    for (int b = 0; b <= id; b += 64) {
         const float v = (b + lane <= id) ? prob[b + lane] : 0.0f;
-        const int cnt = id + 1 - b < 64 ? id + 1 - b : 64;
-        for (int k = 0; k < cnt; k++) {
+        int first = 64;
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
             cdf = cdf + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
-            if (r < cdf) {
-                pick = b + k;
-                break;
-            }
+            const bool c = (r < cdf) && (first == 64) && (b + k <= id);
+            first = c ? k : first;
+        }
+        if (first < 64) {
+            pick = b + first;
+            break;
         }
     }
     int tok;
