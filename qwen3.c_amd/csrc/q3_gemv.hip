@@ -41,6 +41,14 @@ namespace q3k {
 #ifndef Q3_GEMV_PRE
 #define Q3_GEMV_PRE 8
 #endif
+// experiments that did not pay on Qwen3-4B shapes (-2 % / -0.2 %): tiles of at most Q3_GEMV_SMALL wave-loads requested
+// whole before the barrier; Q3_GEMV_BALANCE: 256 workgroups with the tasks dealt evenly instead of ceil(ntasks/tw)
+#ifndef Q3_GEMV_SMALL
+#define Q3_GEMV_SMALL 0
+#endif
+#ifndef Q3_GEMV_BALANCE
+#define Q3_GEMV_BALANCE 0
+#endif
 
 #ifdef Q3_GEMV_STAMPS
 // [0,48): eight phase marks of the first / last wave of three workgroups;
@@ -364,8 +372,10 @@ template <int PRO, int EPI, int NJ, int R>
 __global__ __launch_bounds__(1024) void k_gemv3(Gemv a, int ntasks, int tw, int early8) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NL = R * NJ;
-    constexpr int PRE = NL < Q3_GEMV_PRE ? NL : Q3_GEMV_PRE;      // look-ahead of the streaming loop
-    constexpr int E4 = PRE < 4 ? PRE : 4, E8 = PRE < 8 ? PRE : 8; // requested before the barrier: 4 or 8
+    // look-ahead of the streaming loop: the whole tile when it is small (the launch is then bound by
+    // its prologue, and a load requested after the barrier would add its latency to the tail)
+    constexpr int PRE = NL <= Q3_GEMV_SMALL ? NL : (NL < Q3_GEMV_PRE ? NL : Q3_GEMV_PRE);
+    constexpr int E4 = PRE < 4 ? PRE : 4, E8 = Q3_GEMV_SMALL ? PRE : (PRE < 8 ? PRE : 8);   // requested before the barrier: 4 or all of the look-ahead
     const int n = a.n;
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63;
@@ -386,8 +396,10 @@ __global__ __launch_bounds__(1024) void k_gemv3(Gemv a, int ntasks, int tw, int 
         return;
     }
 
-    int task = (int)blockIdx.x * tw + (uwave - nn);
-    if (task > ntasks) task = ntasks;            // rows >= d read as zero through the descriptor
+    // tasks are dealt evenly: workgroup i owns [i*ntasks/G, (i+1)*ntasks/G), at most tw of them
+    const int tfirst = (int)(((long long)blockIdx.x * ntasks) / gridDim.x);
+    const int tcount = (int)(((long long)(blockIdx.x + 1) * ntasks) / gridDim.x) - tfirst;
+    int task = (uwave - nn < tcount) ? tfirst + (uwave - nn) : ntasks;   // rows >= d read as zero through the descriptor
     const int row0 = task * R;
     float res[R];
     if (EPI == EPI_RESID) {
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(1024) void k_gemv3(Gemv a, int ntasks, int tw, int 
     // A CU takes in ~40 KB of requests at once and ~27 KB/us after the first bytes are back
     // (~2 us); a wave that tries to request more just sits in the issue stage, and the barrier
     // below would wait for it.  So only as much as the CU accepts by the time the activation is
-    // ready (4 or 8 wave-loads per wave, by the number of streaming waves) goes out before the
+    // ready (4 wave-loads per wave, or the whole look-ahead when there are few streaming waves) goes out before the
     // barrier, the rest of the look-ahead right after it.
 #pragma unroll
     for (int q = 0; q < E4; q++) tile_issue_one<R, NJ>(T, wd, tl, row0, q / NJ, q % NJ);
@@ -548,7 +560,7 @@ static Plan make_plan(int d, int n, bool pairs, Pro pro) {
             p.R = R;
             p.TW = tw;
             p.NW = tw + nn;
-            p.grid = (ntasks + tw - 1) / tw;
+            p.grid = (Q3_GEMV_BALANCE && ntasks >= ncu) ? ncu : (ntasks + tw - 1) / tw;     // tasks are dealt evenly over the grid
             p.loop = false;
         }
     }
