@@ -161,3 +161,29 @@ def test_model_created_by_the_reference_loader_is_accepted(hip, host, orc):
     hip.q3_device_detach(mr)
     ref.model_free(mr)
     host.q3_model_close(mo)
+
+
+# (dim, hidden_dim, n_heads, n_kv_heads): the layer shapes of the Qwen3 family, 2 layers, small vocabulary.
+# Each picks a different launch plan in q3_gemv.hip (rows per wave, preparing waves, the generic
+# kernel for hidden sizes beyond 16384), so each is checked bit for bit.
+FAMILY = {"0.6B": (1024, 3072, 16, 8), "1.7B": (2048, 6144, 16, 8), "4B": (2560, 9728, 32, 8),
+          "8B": (4096, 12288, 32, 8), "14B": (5120, 17408, 40, 8), "32B": (5120, 25600, 64, 8)}
+
+
+@pytest.mark.parametrize("family", sorted(FAMILY))
+def test_family_layer_shapes_bit_exact(hip, host, orc, family):
+    dim, hid, heads, kv = FAMILY[family]
+    path = os.path.join(Q.tmp_dir(), f"shape_{family}.bin")
+    Q.synth("4Bmini", path, dim=dim, hidden_dim=hid, n_heads=heads, n_kv_heads=kv, n_layers=2,
+            vocab_size=2048, seq_len=256)
+    mg = hip.q3_model_open(path.encode(), 0, 0)
+    mo = host.q3_model_open(path.encode(), 0, 1)
+    orc.orc_set_mode(Q.ORC_TREE)
+    orc.orc_set_threads(8)
+    feed = np.random.default_rng(3).integers(0, 2048, size=8)
+    for pos in range(8):
+        lg = Q.logits_array(mg, hip.forward(mg, int(feed[pos]), pos))
+        lo = Q.logits_array(mo, orc.orc_forward(mo, int(feed[pos]), pos))
+        assert np.array_equal(lg, lo), (family, pos)
+    hip.q3_model_close(mg)
+    host.q3_model_close(mo)
