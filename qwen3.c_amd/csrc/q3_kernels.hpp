@@ -90,6 +90,16 @@ void swiglu(const float* g, const float* u, int n, float* out, hipStream_t st);
 void expf_map(const float* x, int n, float* out, hipStream_t st);
 void fill_random(float* p, size_t n, uint64_t seed, hipStream_t st);
 
+// ---- batched prompt ingestion (q3_prefill.hip) --------------------------------------------
+// (rmsnorm with weight `w` when non-null, then) q8_quantize of `rows` activation rows of n floats
+void rows_quantize(const float* x, int ldx, const float* w, int n, int rows, int8_t* q, float* s, hipStream_t st);
+// out[t][r] (leading dimension ldo) = W[r][:] . x_t for t < ntok <= 16, on int8 MFMA, bit-identical to
+// gemv() per token; epilogues as in gemv()
+void gemm_q8(const int8_t* W, const float* S, int n, int d, const int8_t* xq, const float* xs, int ntok, float* out,
+             int ldo, Epi epi, hipStream_t st);
+void prefill_begin(const int* tokens, int ntok, int pos0, const int8_t* eq, const float* es, int dim, float* x, int ldx,
+                   const float* rope, int hd, float* cs, Ctl* ctl, hipStream_t st);
+
 // ---- device-side sampling (q3_sample.hip) -----------------------------------------------
 #define Q3_SAMPLE_MAX_CHUNKS 1024
 struct SampleBufs {

@@ -112,6 +112,12 @@ struct Dev {
     size_t cache_floats = 0;      // floats of one stream's K (or V) cache of one layer
     std::vector<hipGraphExec_t> pgexec;   // [stream*3 + AttMode], step without the ctl upload
     int* ptokens = nullptr;       // last stage: [n_streams][cap] chosen tokens
+    // batched prompt ingestion (q3_prefill.hip): buffers for one chunk of 16 positions
+    bool pf_ready = false;
+    int* pf_tokens = nullptr;
+    q3k::Ctl* pf_ctl = nullptr;
+    float *pf_cs = nullptr, *pf_x = nullptr, *pf_qkv = nullptr, *pf_h = nullptr, *pf_as = nullptr, *pf_xs = nullptr;
+    int8_t *pf_aq = nullptr, *pf_xq = nullptr;
     // device-side sampling (q3_sample.hip)
     q3k::SampleBufs sb = {};
     bool sb_ready = false;
@@ -973,6 +979,83 @@ int q3_generate_greedy(Model* m, int token, int pos, int n, int* out_tokens) {
     return n;
 }
 
+// ---- batched prompt ingestion ------------------------------------------
+#define Q3_PF_CHUNK 16
+namespace {
+void ensure_prefill(Dev* d) {
+    if (d->pf_ready) return;
+    const int B = Q3_PF_CHUNK;
+    int wide = d->dim > d->hid ? d->dim : d->hid;
+    if (d->P > wide) wide = d->P;
+    d->pf_tokens = dalloc<int>(d, B);
+    d->pf_ctl = dalloc<q3k::Ctl>(d, B);
+    d->pf_cs = dalloc<float>(d, (size_t)B * d->hd);
+    d->pf_x = dalloc<float>(d, (size_t)B * d->dim);
+    d->pf_qkv = dalloc<float>(d, (size_t)B * (d->P + 2 * d->KVD));
+    d->pf_h = dalloc<float>(d, (size_t)B * d->hid);
+    d->pf_aq = dalloc<int8_t>(d, (size_t)B * d->P);
+    d->pf_as = dalloc<float>(d, (size_t)B * d->P / 64);
+    d->pf_xq = dalloc<int8_t>(d, (size_t)B * wide);
+    d->pf_xs = dalloc<float>(d, (size_t)B * wide / 64);
+    d->pf_ready = true;
+}
+
+// one chunk of bc <= 16 consecutive positions through every layer of this device
+void prefill_chunk(Dev* d, const int* tokens, int bc, int pos0) {
+    const int QKV = d->P + 2 * d->KVD;
+    HIPCHK(hipMemcpyAsync(d->pf_tokens, tokens, (size_t)bc * sizeof(int), hipMemcpyHostToDevice, d->st));
+    q3k::prefill_begin(d->pf_tokens, bc, pos0, d->emb_q, d->emb_s, d->dim, d->pf_x, d->dim, d->rope, d->hd, d->pf_cs,
+                       d->pf_ctl, d->st);
+    for (int l = d->l0; l < d->l1; l++) {
+        const LayerDev& L = d->layers[l];
+        // rmsnorm + quantise of the 16 residual rows, then Wq|Wk|Wv on the matrix cores (forward.c:254-262)
+        q3k::rows_quantize(d->pf_x, d->dim, L.att_nw, d->dim, bc, d->pf_xq, d->pf_xs, d->st);
+        q3k::gemm_q8(L.qkv_q, L.qkv_s, d->dim, QKV, d->pf_xq, d->pf_xs, bc, d->pf_qkv, QKV, q3k::EPI_STORE, d->st);
+        // attention position by position (each appends its k/v, the next one reads it): the decode kernel
+        for (int t = 0; t < bc; t++) {
+            q3k::Attn a = attn_args(d, l, 0);
+            a.ctl = d->pf_ctl + t;
+            a.qkv = d->pf_qkv + (size_t)t * QKV;
+            a.cs = d->pf_cs + (size_t)t * d->hd;
+            a.oq = d->pf_aq + (size_t)t * d->P;
+            a.os = d->pf_as + (size_t)t * (d->P / 64);
+            q3k::attn(a, d->chunk_slots, q3k::attn_mode(pos0 + t), d->st);
+        }
+        q3k::gemm_q8(L.wo_q, L.wo_s, d->P, d->dim, d->pf_aq, d->pf_as, bc, d->pf_x, d->dim, q3k::EPI_RESID, d->st);
+        q3k::rows_quantize(d->pf_x, d->dim, L.ffn_nw, d->dim, bc, d->pf_xq, d->pf_xs, d->st);
+        q3k::gemm_q8(L.gu_q, L.gu_s, d->dim, 2 * d->hid, d->pf_xq, d->pf_xs, bc, d->pf_h, d->hid, q3k::EPI_SWIGLU, d->st);
+        q3k::rows_quantize(d->pf_h, d->hid, nullptr, d->hid, bc, d->pf_xq, d->pf_xs, d->st);
+        q3k::gemm_q8(L.dn_q, L.dn_s, d->hid, d->dim, d->pf_xq, d->pf_xs, bc, d->pf_x, d->dim, q3k::EPI_RESID, d->st);
+    }
+}
+}  // namespace
+
+/* Prompt ingestion: what completion()'s prompt loop (src/completion.c:57-66) does with n calls of
+ * forward(), 16 positions at a time on the matrix cores.  Leaves the KV cache and the returned logits
+ * (those of the last prompt token, in m->state.logits) bit-identical to the n calls. */
+float* q3_prefill(Model* m, const int* tokens, int n, int pos0) {
+    Dev* d = attach(m);
+    if (d->world > 1) Q3_DIE("q3_prefill: single-GPU models only");
+    if (!tokens || n < 1) Q3_DIE("q3_prefill: empty prompt");
+    if (pos0 < 0 || pos0 + n > d->seq) Q3_DIE("q3_prefill: positions [%d,%d) outside the context window [0,%d)", pos0, pos0 + n, d->seq);
+    for (int i = 0; i < n; i++) {
+        if (tokens[i] < 0 || tokens[i] >= d->V) Q3_DIE("q3_prefill: token %d outside the vocabulary [0,%d)", tokens[i], d->V);
+    }
+    HIPCHK(hipSetDevice(d->device));
+    ensure_prefill(d);
+    for (int c0 = 0; c0 < n; c0 += Q3_PF_CHUNK) {
+        const int bc = n - c0 < Q3_PF_CHUNK ? n - c0 : Q3_PF_CHUNK;
+        prefill_chunk(d, tokens + c0, bc, pos0 + c0);
+        if (c0 + bc < n) HIPCHK(hipStreamSynchronize(d->st));      // the token upload buffer is reused
+    }
+    const int last = (n - 1) % Q3_PF_CHUNK;
+    HIPCHK(hipMemcpyAsync(d->x, d->pf_x + (size_t)last * d->dim, (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
+    enqueue_head(d);
+    HIPCHK(hipMemcpyAsync(m->state.logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost, d->st));
+    HIPCHK(hipStreamSynchronize(d->st));
+    return m->state.logits;
+}
+
 // ---- device-side sampling ---------------------------------------------
 namespace {
 void ensure_sampler(Dev* d) {
@@ -1233,6 +1316,17 @@ void q3_op_gemv(const int8_t* wq, const float* ws, const int8_t* xq, const float
     g.W = dw.as<int8_t>(); g.S = dws.as<float>(); g.n = n; g.d = d;
     g.xq = dx.as<int8_t>(); g.xs = dxs.as<float>(); g.out = dout.as<float>();
     q3k::gemv(g, q3k::PRO_Q8, q3k::EPI_STORE, st);
+    dout.to_host(out, st);
+}
+
+// the prefill GEMM (int8 MFMA) on `ntok` <= 16 quantised activation rows: out[t][d]
+void q3_op_gemm(const int8_t* wq, const float* ws, const int8_t* xq, const float* xs, int n, int d, int ntok, float* out) {
+    if (n % 64 || d % 2 || ntok < 1 || ntok > 16) Q3_DIE("gemm: bad shape (n=%d d=%d tokens=%d)", n, d, ntok);
+    hipStream_t st = ops_stream();
+    DBuf dw(wq, (size_t)n * d), dws(ws, (size_t)n * d / 64 * 4), dx(xq, (size_t)n * ntok), dxs(xs, (size_t)n / 64 * 4 * ntok);
+    DBuf dout((size_t)d * 4 * ntok);
+    q3k::gemm_q8(dw.as<int8_t>(), dws.as<float>(), n, d, dx.as<int8_t>(), dxs.as<float>(), ntok, dout.as<float>(), d,
+                 q3k::EPI_STORE, st);
     dout.to_host(out, st);
 }
 

@@ -221,6 +221,10 @@ def hip_lib():
         lib.q3_pipeline_selftest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         lib.q3_pipeline_allreduce_max.restype = C.c_double
         lib.q3_pipeline_allreduce_max.argtypes = [C.c_double]
+        lib.q3_prefill.restype = c_float_p
+        lib.q3_prefill.argtypes = [ModelP, C.POINTER(C.c_int), C.c_int, C.c_int]
+        lib.q3_op_gemm.restype = None
+        lib.q3_op_gemm.argtypes = [c_int8_p, c_float_p, c_int8_p, c_float_p, C.c_int, C.c_int, C.c_int, c_float_p]
         lib.q3_op_sample.restype = C.c_int
         lib.q3_op_sample.argtypes = [c_float_p, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64)]
         lib.q3_device_sample.restype = C.c_int
