@@ -137,7 +137,18 @@ __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks
 
 // HPW = query heads a wave may own (1 when the group has at most 4 query heads)
 template <int HD, int HPW>
-__global__ __launch_bounds__(256, 2) void k_attn(Attn a, int multi) {
+__global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
+    Attn a = a_in;
+    {   // batched prompt ingestion: position blockIdx.z of the launch (all strides 0 for a decode step)
+        const int z = blockIdx.z;
+        a.ctl += z;
+        a.qkv += (size_t)z * a.zs_qkv;
+        a.cs += (size_t)z * a.zs_cs;
+        a.oq += (size_t)z * a.zs_oq;
+        a.os += (size_t)z * a.zs_os;
+        a.part += (size_t)z * a.zs_part;
+        a.tickets += (size_t)z * a.zs_tickets;
+    }
     constexpr int L4 = HD / 4;               // lanes holding one head as float4
     constexpr int CH = Q3_ATT_CHUNK;
     constexpr int NLD = CH * L4 / 256;       // float4 loads per thread per tile
@@ -484,7 +495,15 @@ __device__ __forceinline__ int q8_code1(float y, float scale, float inv) {
     return (int)copysignf(fminf(floorf(t), 127.0f), y);
 }
 template <int HD>
-__global__ __launch_bounds__(64) void k_attn_merge(Attn a) {
+__global__ __launch_bounds__(64) void k_attn_merge(Attn a_in) {
+    Attn a = a_in;
+    {
+        const int z = blockIdx.y;
+        a.ctl += z;
+        a.oq += (size_t)z * a.zs_oq;
+        a.os += (size_t)z * a.zs_os;
+        a.part += (size_t)z * a.zs_part;
+    }
     constexpr int ST = HD + 2;
     constexpr int GPH = HD / 64;                // quantisation groups per head
     const int h = blockIdx.x / GPH, grp = blockIdx.x % GPH;
@@ -534,6 +553,31 @@ __global__ __launch_bounds__(64) void k_attn_merge(Attn a) {
     if (a.of) a.of[(size_t)h * HD + d] = y;
 }
 
+// ---- batched prompt ingestion: the k/v rows of a run of positions, ahead of a batched attn() ----
+template <int HD>
+__global__ __launch_bounds__(64) void k_kv_append(Attn a) {
+    constexpr int L4 = HD / 4;
+    const int g = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const int pos = a.ctl[t].pos;
+    const int P = a.n_heads * HD, KVD = a.n_kv * HD;
+    const float* row = a.qkv + (size_t)t * a.zs_qkv;
+    float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
+    if (lane < L4) {
+        k = *reinterpret_cast<const float4*>(row + P + (size_t)g * HD + 4 * lane);
+        v = *reinterpret_cast<const float4*>(row + P + KVD + (size_t)g * HD + 4 * lane);
+    }
+    k = headnorm_rope_wave<HD>(k, a.knw, a.cs + (size_t)t * a.zs_cs, lane);
+    if (lane < L4) {
+        const size_t off = ((size_t)g * a.seq_len + pos) * HD + 4 * lane;
+        *reinterpret_cast<float4*>(a.kc + off) = k;
+        *reinterpret_cast<float4*>(a.vc + off) = v;
+    }
+}
+void kv_append(const Attn& a, int ntok, hipStream_t st) {
+    if (a.hd == 128) hipLaunchKernelGGL(k_kv_append<128>, dim3(a.n_kv, ntok), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(k_kv_append<64>, dim3(a.n_kv, ntok), dim3(64), 0, st, a);
+}
+
 void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st) {
     if (a.n_heads / a.n_kv > Q3_MAXG) {
         fprintf(stderr, "[q3hip] attention: more than %d query heads per kv head\n", Q3_MAXG);
@@ -543,15 +587,16 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st) {
         fprintf(stderr, "[q3hip] attention: head_dim %d not supported (64 or 128)\n", a.hd);
         exit(EXIT_FAILURE);
     }
-    dim3 grid(a.n_kv, mode == ATT_SINGLE ? 1 : chunk_slots);
+    const int nz = a.nz > 1 ? a.nz : 1;
+    dim3 grid(a.n_kv, mode == ATT_SINGLE ? 1 : chunk_slots, nz);
     const bool two = a.n_heads / a.n_kv > 4;
     if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn<128, 1>), grid, dim3(256), 0, st, a, (int)mode);
     else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, (int)mode);
     else if (!two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, (int)mode);
     else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a, (int)mode);
     if (mode == ATT_LONG) {
-        if (a.hd == 128) hipLaunchKernelGGL(k_attn_merge<128>, dim3(a.n_heads * 2), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(k_attn_merge<64>, dim3(a.n_heads), dim3(64), 0, st, a);
+        if (a.hd == 128) hipLaunchKernelGGL(k_attn_merge<128>, dim3(a.n_heads * 2, nz), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(k_attn_merge<64>, dim3(a.n_heads, nz), dim3(64), 0, st, a);
     }
 }
 

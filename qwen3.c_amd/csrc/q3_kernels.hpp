@@ -54,7 +54,16 @@ struct Attn {
     int n_heads, n_kv, hd, seq_len, max_chunks;
     unsigned long long* stamps;  // diagnostic builds only: s_memrealtime/s_memtime marks of workgroup (0,0)
     int prepared;        // op-level test hook only: q and the k/v of `pos` are already normed + rotated
+    // Batched prompt ingestion: one launch serves nz consecutive positions (grid.z); position z uses
+    // ctl[z], qkv + z*zs_qkv, cs + z*zs_cs, oq + z*zs_oq, os + z*zs_os, part + z*zs_part, tickets + z*zs_tickets.
+    // Their k/v rows must already be in the cache (kv_append): a later position reads an earlier one's.
+    int nz;              // 0 or 1 = a single position
+    int zs_qkv, zs_cs, zs_oq, zs_os, zs_tickets;
+    size_t zs_part;
 };
+// k (head norm + RoPE) and v of `ntok` consecutive positions into the cache (reference forward.c:270-286),
+// ahead of a batched attn(): qkv rows of stride zs_qkv, (cos,sin) rows of stride hd, positions from ctl[t].pos
+void kv_append(const Attn& a, int ntok, hipStream_t st);
 // `chunk_slots` workgroups per kv head walk the 64-position chunks of [0,pos].  Three launch
 // shapes, chosen by the position (the graph of a step is built once per shape):
 //   ATT_SINGLE  pos < 64: one chunk, finalised directly (chunk_slots = 1)

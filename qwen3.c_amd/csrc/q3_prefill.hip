@@ -72,13 +72,18 @@ void rows_quantize(const float* x, int ldx, const float* w, int n, int rows, int
 // ---- Q8_0 GEMM on int8 MFMA ----------------------------------------------------------------
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
+// One workgroup = one tile of 16 rows x 16 tokens; its 4 waves split the groups by SUM16 column:
+// wave w owns the columns 4w..4w+3, i.e. groups 16b + 4w .. 16b + 4w + 3 of every block b of sixteen
+// groups -- four consecutive groups, so the group scales come as one float4 per row.  The sixteen
+// column sums then meet in LDS and wave 0 runs the butterfly: the same additions in the same order
+// as one wave doing it all, with four times the waves streaming the matrix.
 template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_q8(const int8_t* __restrict__ W, const float* __restrict__ S, int n, int d,
                                                  const int8_t* __restrict__ xq, const float* __restrict__ xs, int ntok,
                                                  float* __restrict__ out, int ldo) {
+    __shared__ float cols[16][4][64];           // [column][output register][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = ((int)blockIdx.x * 4 + wave) * 16;
-    if (r0 >= d) return;
+    const int r0 = (int)blockIdx.x * 16;
     const int ng = n >> 6;
     const int li = lane & 15, kb = lane >> 4;
     // A: row r0 + li (clamped: rows >= d are computed and dropped), 16 bytes at k-block kb of each group
@@ -88,44 +93,73 @@ __global__ __launch_bounds__(256) void k_gemm_q8(const int8_t* __restrict__ W, c
     const int tok = li < ntok ? li : ntok - 1;
     const int8_t* bp = xq + (size_t)tok * n + 16 * kb;
     const float* xsp = xs + (size_t)tok * ng;
-    // the 4 output rows of this lane
-    const float* wsp[4];
+    const float* wsp[4];                         // scales of the 4 output rows of this lane
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r = r0 + 4 * kb + i < d ? r0 + 4 * kb + i : d - 1;
         wsp[i] = S + (size_t)r * ng;
     }
-    float col[16][4];            // SUM16: column partial c collects groups g = c, c+16, ... in ascending order
+    float col[4][4];                             // [column 4w + c][output register]
 #pragma unroll
-    for (int c = 0; c < 16; c++)
+    for (int c = 0; c < 4; c++)
 #pragma unroll
         for (int i = 0; i < 4; i++) col[c][i] = 0.0f;
 
-    for (int g0 = 0; g0 < ng; g0 += 16) {
+    for (int g0 = 4 * wave; g0 < ng; g0 += 16) {             // groups g0 .. g0+3 (ng is a multiple of ... any: guarded)
+        v4i a[4], b[4];
+        float4 sw[4], sx;
+        const bool full = g0 + 3 < ng;                        // wave-uniform
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const int g = g0 + c;
-            if (g < ng) {                                   // wave-uniform
-                const v4i a = *reinterpret_cast<const v4i*>(ap + (size_t)g * 64);
-                const v4i b = *reinterpret_cast<const v4i*>(bp + (size_t)g * 64);
-                const float sx = xsp[g];
+        for (int c = 0; c < 4; c++) {
+            const int g = g0 + c < ng ? g0 + c : ng - 1;
+            a[c] = *reinterpret_cast<const v4i*>(ap + (size_t)g * 64);
+            b[c] = *reinterpret_cast<const v4i*>(bp + (size_t)g * 64);
+        }
+        if (full && (ng & 3) == 0) {                          // 16-byte aligned scale quads
+#pragma unroll
+            for (int i = 0; i < 4; i++) sw[i] = *reinterpret_cast<const float4*>(wsp[i] + g0);
+            sx = *reinterpret_cast<const float4*>(xsp + g0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                sw[i].x = wsp[i][g0 < ng ? g0 : ng - 1];
+                sw[i].y = wsp[i][g0 + 1 < ng ? g0 + 1 : ng - 1];
+                sw[i].z = wsp[i][g0 + 2 < ng ? g0 + 2 : ng - 1];
+                sw[i].w = wsp[i][g0 + 3 < ng ? g0 + 3 : ng - 1];
+            }
+            sx.x = xsp[g0 < ng ? g0 : ng - 1];
+            sx.y = xsp[g0 + 1 < ng ? g0 + 1 : ng - 1];
+            sx.z = xsp[g0 + 2 < ng ? g0 + 2 : ng - 1];
+            sx.w = xsp[g0 + 3 < ng ? g0 + 3 : ng - 1];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (g0 + c < ng) {                                // wave-uniform
                 const v4i32 zero = {0, 0, 0, 0};
-                const v4i32 dsum = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, zero, 0, 0, 0);
+                const v4i32 dsum = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], b[c], zero, 0, 0, 0);
+                const float sxc = c == 0 ? sx.x : (c == 1 ? sx.y : (c == 2 ? sx.z : sx.w));
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const float p = ((float)dsum[i] * wsp[i][g]) * sx;
+                    const float swc = c == 0 ? sw[i].x : (c == 1 ? sw[i].y : (c == 2 ? sw[i].z : sw[i].w));
+                    const float p = ((float)dsum[i] * swc) * sxc;
                     col[c][i] = col[c][i] + p;
                 }
             }
         }
     }
-    // butterfly col[c] += col[c^8], ^4, ^2, ^1 (all sixteen partials sit in this lane's registers)
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) cols[4 * wave + c][i][lane] = col[c][i];
+    __syncthreads();
+    if (wave != 0) return;
+    // butterfly col[c] += col[c^8], ^4, ^2, ^1
     float res[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         float t8[8], t4[4], t2[2];
 #pragma unroll
-        for (int c = 0; c < 8; c++) t8[c] = col[c][i] + col[c + 8][i];
+        for (int c = 0; c < 8; c++) t8[c] = cols[c][i][lane] + cols[c + 8][i][lane];
 #pragma unroll
         for (int c = 0; c < 4; c++) t4[c] = t8[c] + t8[c + 4];
 #pragma unroll
@@ -154,7 +188,7 @@ void gemm_q8(const int8_t* W, const float* S, int n, int d, const int8_t* xq, co
         fprintf(stderr, "[q3hip] gemm_q8: bad shape (n=%d d=%d tokens=%d)\n", n, d, ntok);
         exit(EXIT_FAILURE);
     }
-    const dim3 grid((d + 63) / 64), block(256);
+    const dim3 grid((d + 15) / 16), block(256);
     if (epi == EPI_STORE) hipLaunchKernelGGL(k_gemm_q8<EPI_STORE>, grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
     else if (epi == EPI_RESID) hipLaunchKernelGGL(k_gemm_q8<EPI_RESID>, grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
     else hipLaunchKernelGGL(k_gemm_q8<EPI_SWIGLU>, grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);

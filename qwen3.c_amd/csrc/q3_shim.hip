@@ -117,6 +117,8 @@ struct Dev {
     int* pf_tokens = nullptr;
     q3k::Ctl* pf_ctl = nullptr;
     float *pf_cs = nullptr, *pf_x = nullptr, *pf_qkv = nullptr, *pf_h = nullptr, *pf_as = nullptr, *pf_xs = nullptr;
+    float* pf_part = nullptr;     // chunk partials of 16 positions
+    unsigned* pf_tickets = nullptr;
     int8_t *pf_aq = nullptr, *pf_xq = nullptr;
     // device-side sampling (q3_sample.hip)
     q3k::SampleBufs sb = {};
@@ -506,6 +508,7 @@ void prof_collect(Dev* d) {
 q3k::Attn attn_args(Dev* d, int l, int stream = 0) {
     const LayerDev& L = d->layers[l];
     q3k::Attn a;
+    memset(&a, 0, sizeof(a));      // single position: nz and every z stride 0
     a.ctl = d->ctl; a.qkv = d->qkv; a.qnw = L.qnw; a.knw = L.knw; a.cs = d->cs_cur;
     a.kc = L.kc + (size_t)stream * d->cache_floats; a.vc = L.vc + (size_t)stream * d->cache_floats; a.part = d->part;
     a.tickets = d->tickets; a.oq = d->att_q; a.os = d->att_s;
@@ -997,6 +1000,9 @@ void ensure_prefill(Dev* d) {
     d->pf_as = dalloc<float>(d, (size_t)B * d->P / 64);
     d->pf_xq = dalloc<int8_t>(d, (size_t)B * wide);
     d->pf_xs = dalloc<float>(d, (size_t)B * wide / 64);
+    d->pf_part = dalloc<float>(d, (size_t)B * d->H * d->max_chunks * (d->hd + 2));
+    d->pf_tickets = dalloc<unsigned>(d, (size_t)B * d->KV);
+    HIPCHK(hipMemsetAsync(d->pf_tickets, 0, (size_t)B * d->KV * sizeof(unsigned), d->st));
     d->pf_ready = true;
 }
 
@@ -1011,15 +1017,27 @@ void prefill_chunk(Dev* d, const int* tokens, int bc, int pos0) {
         // rmsnorm + quantise of the 16 residual rows, then Wq|Wk|Wv on the matrix cores (forward.c:254-262)
         q3k::rows_quantize(d->pf_x, d->dim, L.att_nw, d->dim, bc, d->pf_xq, d->pf_xs, d->st);
         q3k::gemm_q8(L.qkv_q, L.qkv_s, d->dim, QKV, d->pf_xq, d->pf_xs, bc, d->pf_qkv, QKV, q3k::EPI_STORE, d->st);
-        // attention position by position (each appends its k/v, the next one reads it): the decode kernel
-        for (int t = 0; t < bc; t++) {
+        // k/v of all the positions into the cache first (a later position attends to an earlier one's),
+        // then the decode attention kernel with one grid layer per position -- one launch per run of
+        // positions that share a launch shape
+        {
             q3k::Attn a = attn_args(d, l, 0);
-            a.ctl = d->pf_ctl + t;
-            a.qkv = d->pf_qkv + (size_t)t * QKV;
-            a.cs = d->pf_cs + (size_t)t * d->hd;
-            a.oq = d->pf_aq + (size_t)t * d->P;
-            a.os = d->pf_as + (size_t)t * (d->P / 64);
-            q3k::attn(a, d->chunk_slots, q3k::attn_mode(pos0 + t), d->st);
+            a.ctl = d->pf_ctl; a.qkv = d->pf_qkv; a.cs = d->pf_cs; a.oq = d->pf_aq; a.os = d->pf_as;
+            a.part = d->pf_part; a.tickets = d->pf_tickets;
+            a.zs_qkv = QKV; a.zs_cs = d->hd; a.zs_oq = d->P; a.zs_os = d->P / 64; a.zs_tickets = d->KV;
+            a.zs_part = (size_t)d->H * d->max_chunks * (d->hd + 2);
+            q3k::kv_append(a, bc, d->st);
+            for (int t0 = 0; t0 < bc;) {
+                const q3k::AttMode mode = q3k::attn_mode(pos0 + t0);
+                int t1 = t0 + 1;
+                while (t1 < bc && q3k::attn_mode(pos0 + t1) == mode) t1++;
+                q3k::Attn b = a;
+                b.ctl += t0; b.qkv += (size_t)t0 * a.zs_qkv; b.cs += (size_t)t0 * a.zs_cs; b.oq += (size_t)t0 * a.zs_oq;
+                b.os += (size_t)t0 * a.zs_os; b.part += (size_t)t0 * a.zs_part; b.tickets += (size_t)t0 * a.zs_tickets;
+                b.nz = t1 - t0;
+                q3k::attn(b, d->chunk_slots, mode, d->st);
+                t0 = t1;
+            }
         }
         q3k::gemm_q8(L.wo_q, L.wo_s, d->P, d->dim, d->pf_aq, d->pf_as, bc, d->pf_x, d->dim, q3k::EPI_RESID, d->st);
         q3k::rows_quantize(d->pf_x, d->dim, L.ffn_nw, d->dim, bc, d->pf_xq, d->pf_xs, d->st);
