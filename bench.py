@@ -228,6 +228,16 @@ def main():
         hip.q3_pipeline_run(m, tok, pos + 8, K); hip.q3_device_sync(m)
         out["device_loop_tokens_per_s"] = round(K / (time.perf_counter() - t0), 2)
         pos += 8 + K
+    if ngpu == 1 and pos + 600 < seq:
+        # prompt ingestion (q3_prefill: 16 positions per pass, Q8_0 products on int8 MFMA; bit-identical
+        # to feeding the prompt through forward()) -- reported next to the decode rate, not part of `value`
+        n_pf = 256
+        prompt = (C.c_int * n_pf)(*[int(t) for t in np.random.default_rng(5).integers(0, vocab, size=n_pf)])
+        hip.q3_prefill(m, prompt, 32, pos)
+        t0 = time.perf_counter()
+        hip.q3_prefill(m, prompt, n_pf, pos)
+        out["prefill_tokens_per_s"] = round(n_pf / (time.perf_counter() - t0), 1)
+        pos += n_pf
     if rank == 0 and ngpu == 1 and not args.no_roofline:
         hip.q3_prof_enable(m, 1)
         hip.q3_prof_reset(m)
