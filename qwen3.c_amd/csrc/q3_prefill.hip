@@ -78,7 +78,7 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 // column sums then meet in LDS and wave 0 runs the butterfly: the same additions in the same order
 // as one wave doing it all, with four times the waves streaming the matrix.
 template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_q8(const int8_t* __restrict__ W, const float* __restrict__ S, int n, int d,
+__global__ __launch_bounds__(256, 4) void k_gemm_q8(const int8_t* __restrict__ W, const float* __restrict__ S, int n, int d,
                                                  const int8_t* __restrict__ xq, const float* __restrict__ xs, int ntok,
                                                  float* __restrict__ out, int ldo) {
     __shared__ float cols[16][4][64];           // [column][output register][lane]
