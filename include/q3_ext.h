@@ -100,7 +100,7 @@ int q3_generate_greedy(Model* m, int token, int pos, int n, int* out_tokens);
 
 /* Batched prompt ingestion (no counterpart call in the reference, whose completion() feeds the
  * prompt through forward() one token at a time, src/completion.c:57-66): positions pos0..pos0+n-1
- * take `tokens`, 16 at a time, the Q8_0 products on the int8 matrix cores.  The KV cache and the
+ * take `tokens`, 64 at a time, the Q8_0 products on the int8 matrix cores.  The KV cache and the
  * returned logits (of the last prompt token; m->state.logits, host memory) are bit-identical to n
  * calls of forward(). */
 float* q3_prefill(Model* m, const int* tokens, int n, int pos0);
@@ -144,7 +144,7 @@ void q3_op_attention(const float* q, const float* kcache, const float* vcache, i
                      int n_heads, int n_kv_heads, int head_dim, float* out);
 void q3_op_swiglu(const float* gate, const float* up, int n, float* out);
 void q3_op_expf(const float* x, int n, float* out);
-/* The prefill GEMM (int8 MFMA) on ntok <= 16 quantised activation rows xq[ntok][n] / xs[ntok][n/64]:
+/* The prefill GEMM (int8 MFMA) on ntok <= 64 quantised activation rows xq[ntok][n] / xs[ntok][n/64]:
  * out[t][d] = matmul() of row t (reference src/forward.c:79-101), bit-identical to q3_op_gemv per row. */
 void q3_op_gemm(const int8_t* wq, const float* ws, const int8_t* xq, const float* xs, int n, int d, int ntok, float* out);
 /* reference sample() (src/sampler.c:189-201) on host logits through the device sampler: returns the

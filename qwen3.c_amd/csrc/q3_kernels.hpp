@@ -102,7 +102,7 @@ void fill_random(float* p, size_t n, uint64_t seed, hipStream_t st);
 // ---- batched prompt ingestion (q3_prefill.hip) --------------------------------------------
 // (rmsnorm with weight `w` when non-null, then) q8_quantize of `rows` activation rows of n floats
 void rows_quantize(const float* x, int ldx, const float* w, int n, int rows, int8_t* q, float* s, hipStream_t st);
-// out[t][r] (leading dimension ldo) = W[r][:] . x_t for t < ntok <= 16, on int8 MFMA, bit-identical to
+// out[t][r] (leading dimension ldo) = W[r][:] . x_t for t < ntok <= 64, on int8 MFMA, bit-identical to
 // gemv() per token; epilogues as in gemv()
 void gemm_q8(const int8_t* W, const float* S, int n, int d, const int8_t* xq, const float* xs, int ntok, float* out,
              int ldo, Epi epi, hipStream_t st);

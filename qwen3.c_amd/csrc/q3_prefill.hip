@@ -1,5 +1,5 @@
-// q3_prefill.hip -- batched prompt ingestion: up to 16 prompt positions go
-// through a layer together, so every weight byte is read once per 16 tokens instead of once per
+// q3_prefill.hip -- batched prompt ingestion: up to 64 prompt positions go
+// through a layer together, so every weight byte is read once per 64 tokens instead of once per
 // token, and the Q8_0 product runs on the matrix cores.
 //
 //   k_rows_quantize   the GEMV prologue (rmsnorm + q8_quantize, or q8_quantize alone) for B
@@ -77,11 +77,12 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 // groups -- four consecutive groups, so the group scales come as one float4 per row.  The sixteen
 // column sums then meet in LDS and wave 0 runs the butterfly: the same additions in the same order
 // as one wave doing it all, with four times the waves streaming the matrix.
-template <int EPI>
-__global__ __launch_bounds__(256, 4) void k_gemm_q8(const int8_t* __restrict__ W, const float* __restrict__ S, int n, int d,
-                                                 const int8_t* __restrict__ xq, const float* __restrict__ xs, int ntok,
-                                                 float* __restrict__ out, int ldo) {
-    __shared__ float cols[16][4][64];           // [column][output register][lane]
+template <int EPI, int NT>            // NT = token tiles of 16 per workgroup: the weights are loaded once for all of them
+__global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 2 : 1)) void k_gemm_q8(const int8_t* __restrict__ W, const float* __restrict__ S, int n,
+                                                                  int d, const int8_t* __restrict__ xq,
+                                                                  const float* __restrict__ xs, int ntok,
+                                                                  float* __restrict__ out, int ldo) {
+    __shared__ float cols[NT][16][4][64];       // [token tile][column][output register][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = (int)blockIdx.x * 16;
     const int ng = n >> 6;
@@ -89,92 +90,102 @@ __global__ __launch_bounds__(256, 4) void k_gemm_q8(const int8_t* __restrict__ W
     // A: row r0 + li (clamped: rows >= d are computed and dropped), 16 bytes at k-block kb of each group
     const int arow = r0 + li < d ? r0 + li : d - 1;
     const int8_t* ap = W + (size_t)arow * n + 16 * kb;
-    // B: token li (tokens >= ntok: clamped, dropped at the store)
-    const int tok = li < ntok ? li : ntok - 1;
-    const int8_t* bp = xq + (size_t)tok * n + 16 * kb;
-    const float* xsp = xs + (size_t)tok * ng;
+    // B: token 16j + li of tile j (tokens >= ntok: clamped, dropped at the store)
+    const int8_t* bp[NT];
+    const float* xsp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int tok = 16 * j + li < ntok ? 16 * j + li : ntok - 1;
+        bp[j] = xq + (size_t)tok * n + 16 * kb;
+        xsp[j] = xs + (size_t)tok * ng;
+    }
     const float* wsp[4];                         // scales of the 4 output rows of this lane
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r = r0 + 4 * kb + i < d ? r0 + 4 * kb + i : d - 1;
         wsp[i] = S + (size_t)r * ng;
     }
-    float col[4][4];                             // [column 4w + c][output register]
+    float col[NT][4][4];                         // [token tile][column 4w + c][output register]
 #pragma unroll
-    for (int c = 0; c < 4; c++)
+    for (int j = 0; j < NT; j++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) col[c][i] = 0.0f;
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[j][c][i] = 0.0f;
 
-    for (int g0 = 4 * wave; g0 < ng; g0 += 16) {             // groups g0 .. g0+3 (ng is a multiple of ... any: guarded)
-        v4i a[4], b[4];
-        float4 sw[4], sx;
-        const bool full = g0 + 3 < ng;                        // wave-uniform
+    for (int g0 = 4 * wave; g0 < ng; g0 += 16) {             // groups g0 .. g0+3
+        v4i a[4], b[NT][4];
+        float4 sw[4], sx[NT];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int g = g0 + c < ng ? g0 + c : ng - 1;
             a[c] = *reinterpret_cast<const v4i*>(ap + (size_t)g * 64);
-            b[c] = *reinterpret_cast<const v4i*>(bp + (size_t)g * 64);
+#pragma unroll
+            for (int j = 0; j < NT; j++) b[j][c] = *reinterpret_cast<const v4i*>(bp[j] + (size_t)g * 64);
         }
-        if (full && (ng & 3) == 0) {                          // 16-byte aligned scale quads
+        if (g0 + 3 < ng && (ng & 3) == 0) {                   // 16-byte aligned scale quads
 #pragma unroll
             for (int i = 0; i < 4; i++) sw[i] = *reinterpret_cast<const float4*>(wsp[i] + g0);
-            sx = *reinterpret_cast<const float4*>(xsp + g0);
-        } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                sw[i].x = wsp[i][g0 < ng ? g0 : ng - 1];
-                sw[i].y = wsp[i][g0 + 1 < ng ? g0 + 1 : ng - 1];
-                sw[i].z = wsp[i][g0 + 2 < ng ? g0 + 2 : ng - 1];
-                sw[i].w = wsp[i][g0 + 3 < ng ? g0 + 3 : ng - 1];
-            }
-            sx.x = xsp[g0 < ng ? g0 : ng - 1];
-            sx.y = xsp[g0 + 1 < ng ? g0 + 1 : ng - 1];
-            sx.z = xsp[g0 + 2 < ng ? g0 + 2 : ng - 1];
-            sx.w = xsp[g0 + 3 < ng ? g0 + 3 : ng - 1];
+            for (int j = 0; j < NT; j++) sx[j] = *reinterpret_cast<const float4*>(xsp[j] + g0);
+        } else {
+            const int g1 = g0 < ng ? g0 : ng - 1, g2 = g0 + 1 < ng ? g0 + 1 : ng - 1;
+            const int g3 = g0 + 2 < ng ? g0 + 2 : ng - 1, g4 = g0 + 3 < ng ? g0 + 3 : ng - 1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) sw[i] = make_float4(wsp[i][g1], wsp[i][g2], wsp[i][g3], wsp[i][g4]);
+#pragma unroll
+            for (int j = 0; j < NT; j++) sx[j] = make_float4(xsp[j][g1], xsp[j][g2], xsp[j][g3], xsp[j][g4]);
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             if (g0 + c < ng) {                                // wave-uniform
-                const v4i32 zero = {0, 0, 0, 0};
-                const v4i32 dsum = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], b[c], zero, 0, 0, 0);
-                const float sxc = c == 0 ? sx.x : (c == 1 ? sx.y : (c == 2 ? sx.z : sx.w));
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float swc = c == 0 ? sw[i].x : (c == 1 ? sw[i].y : (c == 2 ? sw[i].z : sw[i].w));
-                    const float p = ((float)dsum[i] * swc) * sxc;
-                    col[c][i] = col[c][i] + p;
+                for (int j = 0; j < NT; j++) {
+                    const v4i32 zero = {0, 0, 0, 0};
+                    const v4i32 dsum = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], b[j][c], zero, 0, 0, 0);
+                    const float sxc = c == 0 ? sx[j].x : (c == 1 ? sx[j].y : (c == 2 ? sx[j].z : sx[j].w));
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float swc = c == 0 ? sw[i].x : (c == 1 ? sw[i].y : (c == 2 ? sw[i].z : sw[i].w));
+                        const float p = ((float)dsum[i] * swc) * sxc;
+                        col[j][c][i] = col[j][c][i] + p;
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int c = 0; c < 4; c++)
+    for (int j = 0; j < NT; j++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) cols[4 * wave + c][i][lane] = col[c][i];
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) cols[j][4 * wave + c][i][lane] = col[j][c][i];
     __syncthreads();
-    if (wave != 0) return;
-    // butterfly col[c] += col[c^8], ^4, ^2, ^1
+    if (wave >= NT) return;
+    // wave j finishes token tile j: butterfly col[c] += col[c^8], ^4, ^2, ^1
+    const int j = wave;
     float res[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         float t8[8], t4[4], t2[2];
 #pragma unroll
-        for (int c = 0; c < 8; c++) t8[c] = cols[c][i][lane] + cols[c + 8][i][lane];
+        for (int c = 0; c < 8; c++) t8[c] = cols[j][c][i][lane] + cols[j][c + 8][i][lane];
 #pragma unroll
         for (int c = 0; c < 4; c++) t4[c] = t8[c] + t8[c + 4];
 #pragma unroll
         for (int c = 0; c < 2; c++) t2[c] = t4[c] + t4[c + 2];
         res[i] = t2[0] + t2[1];
     }
-    if (li >= ntok) return;
+    const int tokj = 16 * j + li;
+    if (tokj >= ntok) return;
     const int row = r0 + 4 * kb;
     if (EPI == EPI_SWIGLU) {
         // rows are interleaved (gate_i, up_i): two outputs per lane
-        float* o = out + (size_t)li * ldo + (row >> 1);
+        float* o = out + (size_t)tokj * ldo + (row >> 1);
         if (row < d) o[0] = swiglu_pair(res[0], res[1]);
         if (row + 2 < d) o[1] = swiglu_pair(res[2], res[3]);
     } else {
-        float* o = out + (size_t)li * ldo + row;
+        float* o = out + (size_t)tokj * ldo + row;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (row + i < d) o[i] = (EPI == EPI_RESID) ? o[i] + res[i] : res[i];
@@ -182,16 +193,23 @@ __global__ __launch_bounds__(256, 4) void k_gemm_q8(const int8_t* __restrict__ W
     }
 }
 
+template <int NT>
+static void launch_gemm(const int8_t* W, const float* S, int n, int d, const int8_t* xq, const float* xs, int ntok,
+                        float* out, int ldo, Epi epi, hipStream_t st) {
+    const dim3 grid((d + 15) / 16), block(256);
+    if (epi == EPI_STORE) hipLaunchKernelGGL((k_gemm_q8<EPI_STORE, NT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+    else if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_q8<EPI_RESID, NT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+    else hipLaunchKernelGGL((k_gemm_q8<EPI_SWIGLU, NT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+}
 void gemm_q8(const int8_t* W, const float* S, int n, int d, const int8_t* xq, const float* xs, int ntok, float* out,
              int ldo, Epi epi, hipStream_t st) {
-    if (n % 64 || d % 2 || ntok < 1 || ntok > 16) {
+    if (n % 64 || d % 2 || ntok < 1 || ntok > 64) {
         fprintf(stderr, "[q3hip] gemm_q8: bad shape (n=%d d=%d tokens=%d)\n", n, d, ntok);
         exit(EXIT_FAILURE);
     }
-    const dim3 grid((d + 15) / 16), block(256);
-    if (epi == EPI_STORE) hipLaunchKernelGGL(k_gemm_q8<EPI_STORE>, grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
-    else if (epi == EPI_RESID) hipLaunchKernelGGL(k_gemm_q8<EPI_RESID>, grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
-    else hipLaunchKernelGGL(k_gemm_q8<EPI_SWIGLU>, grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+    if (ntok <= 16) launch_gemm<1>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
+    else if (ntok <= 32) launch_gemm<2>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
+    else launch_gemm<4>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
 }
 
 // ---- per-token bookkeeping of a prefill chunk ----------------------------------------------

@@ -983,7 +983,9 @@ int q3_generate_greedy(Model* m, int token, int pos, int n, int* out_tokens) {
 }
 
 // ---- batched prompt ingestion ------------------------------------------
-#define Q3_PF_CHUNK 16
+#ifndef Q3_PF_CHUNK
+#define Q3_PF_CHUNK 64
+#endif
 namespace {
 void ensure_prefill(Dev* d) {
     if (d->pf_ready) return;
@@ -1006,7 +1008,7 @@ void ensure_prefill(Dev* d) {
     d->pf_ready = true;
 }
 
-// one chunk of bc <= 16 consecutive positions through every layer of this device
+// one chunk of bc <= Q3_PF_CHUNK consecutive positions through every layer of this device
 void prefill_chunk(Dev* d, const int* tokens, int bc, int pos0) {
     const int QKV = d->P + 2 * d->KVD;
     HIPCHK(hipMemcpyAsync(d->pf_tokens, tokens, (size_t)bc * sizeof(int), hipMemcpyHostToDevice, d->st));
@@ -1337,9 +1339,9 @@ void q3_op_gemv(const int8_t* wq, const float* ws, const int8_t* xq, const float
     dout.to_host(out, st);
 }
 
-// the prefill GEMM (int8 MFMA) on `ntok` <= 16 quantised activation rows: out[t][d]
+// the prefill GEMM (int8 MFMA) on `ntok` <= 32 quantised activation rows: out[t][d]
 void q3_op_gemm(const int8_t* wq, const float* ws, const int8_t* xq, const float* xs, int n, int d, int ntok, float* out) {
-    if (n % 64 || d % 2 || ntok < 1 || ntok > 16) Q3_DIE("gemm: bad shape (n=%d d=%d tokens=%d)", n, d, ntok);
+    if (n % 64 || d % 2 || ntok < 1 || ntok > 64) Q3_DIE("gemm: bad shape (n=%d d=%d tokens=%d)", n, d, ntok);
     hipStream_t st = ops_stream();
     DBuf dw(wq, (size_t)n * d), dws(ws, (size_t)n * d / 64 * 4), dx(xq, (size_t)n * ntok), dxs(xs, (size_t)n / 64 * 4 * ntok);
     DBuf dout((size_t)d * 4 * ntok);
