@@ -268,7 +268,7 @@ def main():
             ach = round(hip.q3_gemv_bytes(2 * p.hidden_dim, p.dim) / us_best / 1e3, 1)
             traffic = None
             try:   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")))["kernels"]["gateup"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v6_pmc_traffic.json")))["kernels"]["gateup"]
                 if args.model == "4B":
                     traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
             except Exception:
