@@ -296,20 +296,23 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
         const int t0 = c * CH;
         const int Tc = (T - t0 < CH) ? T - t0 : CH;      // valid positions in this chunk
         if (!first) {      // contexts beyond gridDim.y chunks only: the previous chunk's PV is over for this wave
-            // (whole tiles, unconditionally: the cache is padded to a multiple of CH rows, and
-            // predicated accesses would push kt / vt out of registers)
+            // (unconditional loads -- predicated accesses would push kt / vt out of registers -- with the
+            // row clamped to the last valid one, so a short last chunk re-reads one row instead of
+            // pulling 64 KB of unused cache)
 #pragma unroll
             for (int k = 0; k < NLD; k++) {
                 const int idx = tid + k * 256;
                 const int t = idx / L4, l4 = idx - t * L4;
-                kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
+                const int tc = t < Tc ? t : Tc - 1;
+                kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(t0 + tc) * HD + 4 * l4);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < NLD; k++) {
                 const int idx = tid + k * 256;
                 const int t = idx / L4, l4 = idx - t * L4;
-                vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
+                const int tc = t < Tc ? t : Tc - 1;
+                vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(t0 + tc) * HD + 4 * l4);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -511,14 +514,39 @@ __global__ __launch_bounds__(64) void k_attn_merge(Attn a_in) {
     const int nchunks = a.ctl->pos / Q3_ATT_CHUNK + 1;
     const float* base = a.part + (size_t)h * a.max_chunks * ST;
     const int d = grp * 64 + lane;
-    float M = -3.0e38f;
-    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+    // Everything the first 64 chunks need -- their (m_c, l_c) pairs, one per lane, and this lane's
+    // value of each O_c -- is requested in ONE burst: the usual context (<= 4096 positions) costs a
+    // single memory round trip.  Longer contexts walk further blocks of 64 chunks.
+    float2 ml0 = make_float2(-3.0e38f, 0.0f);
+    if (lane < nchunks) ml0 = *reinterpret_cast<const float2*>(base + (size_t)lane * ST + HD);
+    float o0[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) o0[k] = base[(size_t)(k < nchunks ? k : nchunks - 1) * ST + d];
+    float M = wave_max(ml0.x);
+    for (int c0 = 64; c0 < nchunks; c0 += 64) {
         const int c = c0 + lane;
         const float mc = c < nchunks ? base[(size_t)c * ST + HD] : -3.0e38f;
         M = fmaxf(M, wave_max(mc));
     }
     float L = 0.0f, A = 0.0f;
-    for (int c0 = 0; c0 < nchunks; c0 += 64) {
+    {
+        float wc = 0.0f, wl = 0.0f;
+        if (lane < nchunks) {
+            wc = q3_expf(ml0.x - M);
+            wl = wc * ml0.y;
+        }
+        const int cnt = nchunks < 64 ? nchunks : 64;
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+            if (k < cnt) {
+                const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wc), k));
+                const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), k));
+                L = L + t;
+                A = A + w * o0[k];
+            }
+        }
+    }
+    for (int c0 = 64; c0 < nchunks; c0 += 64) {
         const int c = c0 + lane;
         float wc = 0.0f, wl = 0.0f;
         if (c < nchunks) {

@@ -389,7 +389,9 @@ Dev* attach(Model* m) {
     d->att_f = dalloc<float>(d, d->P);
     d->cs_cur = dalloc<float>(d, d->hd);
     d->max_chunks = (d->seq + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK;
-    d->chunk_slots = d->max_chunks < 256 ? d->max_chunks : 256;   // one workgroup per (kv head, chunk) up to 16k positions
+    // one workgroup per (kv head, chunk) up to 4096 positions = 512 workgroups, two per CU; beyond, the
+    // workgroups walk several chunks each instead of queueing a few stragglers behind a full first round
+    d->chunk_slots = d->max_chunks < 64 ? d->max_chunks : 64;
     d->part = dalloc<float>(d, (size_t)d->H * d->max_chunks * (d->hd + 2));
     d->tap_dev = dalloc<float>(d, (size_t)d->L * d->dim);
     d->ctl = dalloc<q3k::Ctl>(d, 1);
@@ -1394,7 +1396,7 @@ void q3_op_attention(const float* q, const float* kcache, const float* vcache, i
     a.oq = doq.as<int8_t>(); a.os = dos.as<float>(); a.of = dof.as<float>(); a.qdbg = nullptr;
     a.n_heads = n_heads; a.n_kv = n_kv_heads; a.hd = hd; a.seq_len = seq; a.max_chunks = max_chunks;
     a.prepared = 1;
-    q3k::attn(a, max_chunks, q3k::attn_mode(T - 1), st);
+    q3k::attn(a, max_chunks < 64 ? max_chunks : 64, q3k::attn_mode(T - 1), st);
     dof.to_host(out, st);
 }
 

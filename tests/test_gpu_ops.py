@@ -116,7 +116,7 @@ def test_headnorm_rope(hip, orc, hd, pos):
     assert np.array_equal(one, exp1)
 
 
-@pytest.mark.parametrize("T", [1, 2, 7, 63, 64, 65, 128, 130, 200, 1000, 1024, 1025, 2100, 4200])
+@pytest.mark.parametrize("T", [1, 2, 7, 63, 64, 65, 128, 130, 200, 1000, 1024, 1025, 2100, 4200, 8300])
 @pytest.mark.parametrize("heads", [(4, 1, 128), (2, 1, 64), (8, 2, 128), (16, 8, 128)])
 def test_attention(hip, orc, T, heads):
     H, KV, hd = heads
