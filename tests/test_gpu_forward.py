@@ -185,5 +185,11 @@ def test_family_layer_shapes_bit_exact(hip, host, orc, family):
         lg = Q.logits_array(mg, hip.forward(mg, int(feed[pos]), pos))
         lo = Q.logits_array(mo, orc.orc_forward(mo, int(feed[pos]), pos))
         assert np.array_equal(lg, lo), (family, pos)
+    # the same positions again through the batched prompt path (int8-MFMA GEMM) on a fresh model
+    mp = hip.q3_model_open(path.encode(), 0, 0)
+    arr = (C.c_int * 8)(*[int(t) for t in feed])
+    lp = Q.logits_array(mp, hip.q3_prefill(mp, arr, 8, 0))
+    assert np.array_equal(lp, lg), family
+    hip.q3_model_close(mp)
     hip.q3_model_close(mg)
     host.q3_model_close(mo)
