@@ -280,11 +280,8 @@ void upload_weights(Dev* d) {
     }
 }
 
-void pipeline_split(int L, int rank, int world, int* first, int* count) {
-    ModelParams p;
-    memset(&p, 0, sizeof(p));
-    p.n_layers = L;
-    q3_pipeline_layers(&p, rank, world, first, count);
+void pipeline_split(const ModelParams* p, int rank, int world, int* first, int* count) {
+    q3_pipeline_layers(p, rank, world, first, count);
 }
 
 // The persistent step kernel: one launch per step instead of ~180 (q3_mega.hip).  Opt-in
@@ -367,7 +364,7 @@ Dev* attach(Model* m) {
     }
     if (d->world > 1) {
         int first, count;
-        pipeline_split(d->L, d->rank, d->world, &first, &count);
+        pipeline_split(p, d->rank, d->world, &first, &count);
         d->l0 = first; d->l1 = first + count;
         d->has_embed = d->rank == 0;
         d->has_cls = d->rank == d->world - 1;

@@ -266,12 +266,38 @@ double q3_bytes_per_token(const ModelParams* p, int T) {
  * Pure arithmetic, kept on the host side so that harnesses and CPU tests can use it
  * without loading the HIP runtime. */
 
-/* contiguous blocks of n_layers/world layers, the first n_layers%world ranks one more */
+/* Contiguous blocks of layers, sized so that the stages take equal TIME per tick: the last stage also
+ * runs the classifier, which on MI355X streams at ~6.2 TB/s while a layer's five launches average
+ * ~2.6 TB/s, so the classifier weighs 0.42 * cls_bytes / layer_bytes layers (1.6 layers at Qwen3-4B,
+ * 67 us against 41 us per layer) and the last stage gets that many layers fewer.  With incomplete
+ * parameters (or fewer layers than stages) the split is the plain even one. */
 void q3_pipeline_layers(const ModelParams* p, int rank, int world, int* first, int* count) {
     const int L = p->n_layers;
-    const int base = L / world, rem = L % world;
-    *count = base + (rank < rem ? 1 : 0);
-    *first = rank * base + (rank < rem ? rank : rem);
+    int cnt_last = -1;
+    if (world > 1 && L >= world && p->dim > 0 && p->hidden_dim > 0 && p->vocab_size > 0 && p->n_heads > 0) {
+        const double P = (double)p->n_heads * p->head_dim, KVD = (double)p->n_kv_heads * p->head_dim;
+        const double layer = (double)p->dim * (P + 2.0 * KVD) + P * p->dim + 3.0 * (double)p->dim * p->hidden_dim;
+        const double cls = 0.42 * (double)p->vocab_size * p->dim / layer;          /* in layers */
+        const double target = ((double)L + cls) / world;
+        cnt_last = (int)(target - cls + 0.5);
+        if (cnt_last < 1) cnt_last = 1;
+        if (cnt_last > L - (world - 1)) cnt_last = L - (world - 1);
+    }
+    if (cnt_last < 0) {
+        const int base = L / world, rem = L % world;
+        *count = base + (rank < rem ? 1 : 0);
+        *first = rank * base + (rank < rem ? rank : rem);
+        return;
+    }
+    const int rest = L - cnt_last, w1 = world - 1;
+    const int base = rest / w1, rem = rest % w1;
+    if (rank == world - 1) {
+        *count = cnt_last;
+        *first = rest;
+    } else {
+        *count = base + (rank < rem ? 1 : 0);
+        *first = rank * base + (rank < rem ? rank : rem);
+    }
 }
 
 /* `world` token streams circulate so that every stage is busy on every tick:
