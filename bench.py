@@ -239,6 +239,10 @@ def main():
         out["prefill_tokens_per_s"] = round(n_pf / (time.perf_counter() - t0), 1)
         pos += n_pf
     if rank == 0 and ngpu == 1 and not args.no_roofline:
+        # the roofline is quoted against the vendor HBM peak; next to it, what a plain device copy reaches here
+        copy = hip.q3_measure_copy_gbps(1 << 30, 8)
+        out["hbm_copy_gbps_measured"] = round(copy, 1)
+        out["frac_of_measured_copy"] = round(per_gpu_rate * bpt / 1e9 / copy, 4)
         hip.q3_prof_enable(m, 1)
         hip.q3_prof_reset(m)
         for _ in range(3):           # untimed: first launches of the non-graph path

@@ -98,6 +98,10 @@ int q3_device_argmax(Model* m);           /* argmax of the device logits */
  * copied to the host only after the last step. */
 int q3_generate_greedy(Model* m, int token, int pos, int n, int* out_tokens);
 
+/* Device-to-device copy rate of the selected GPU in GB/s (bytes read + bytes written), `iters` copies of
+ * `bytes`: the measured companion of the vendor HBM peak in bench.py. */
+double q3_measure_copy_gbps(size_t bytes, int iters);
+
 /* Batched prompt ingestion (no counterpart call in the reference, whose completion() feeds the
  * prompt through forward() one token at a time, src/completion.c:57-66): positions pos0..pos0+n-1
  * take `tokens`, 64 at a time, the Q8_0 products on the int8 matrix cores.  The KV cache and the

@@ -1149,6 +1149,34 @@ int q3_generate_sampled(Model* m, int token, int pos, int n, float temperature, 
     return n;
 }
 
+/* Device-to-device copy rate of this GPU in GB/s, counting the bytes read AND the bytes written
+ * (the roofline is quoted against the vendor peak and against a measured copy). */
+double q3_measure_copy_gbps(size_t bytes, int iters) {
+    die_if_no_gpu();
+    HIPCHK(hipSetDevice(pick_device()));
+    if (bytes < (1u << 20)) bytes = 1u << 20;
+    if (iters < 1) iters = 1;
+    void *a = nullptr, *b = nullptr;
+    HIPCHK(hipMalloc(&a, bytes));
+    HIPCHK(hipMalloc(&b, bytes));
+    HIPCHK(hipMemset(a, 1, bytes));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemcpy(b, a, bytes, hipMemcpyDeviceToDevice));          // warm-up
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; i++) HIPCHK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, nullptr));
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(hipEventDestroy(e0));
+    HIPCHK(hipEventDestroy(e1));
+    HIPCHK(hipFree(a));
+    HIPCHK(hipFree(b));
+    return 2.0 * (double)bytes * iters / ((double)ms * 1e-3) / 1e9;
+}
+
 void q3_kv_fill_random(Model* m, int T, uint64_t seed) {
     Dev* d = attach(m);
     if (T > d->seq) T = d->seq;

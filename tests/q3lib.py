@@ -221,6 +221,8 @@ def hip_lib():
         lib.q3_pipeline_selftest.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         lib.q3_pipeline_allreduce_max.restype = C.c_double
         lib.q3_pipeline_allreduce_max.argtypes = [C.c_double]
+        lib.q3_measure_copy_gbps.restype = C.c_double
+        lib.q3_measure_copy_gbps.argtypes = [C.c_size_t, C.c_int]
         lib.q3_prefill.restype = c_float_p
         lib.q3_prefill.argtypes = [ModelP, C.POINTER(C.c_int), C.c_int, C.c_int]
         lib.q3_op_gemm.restype = None
