@@ -502,6 +502,7 @@ __device__ __forceinline__ void aux_main(const Mega* __restrict__ mp, char* smem
     const int L0 = a.l0, L1 = a.l1;
     const int asub = wave - Q3M_WORKERS;               // 0 / 1
     unsigned t_raw = Q3M_AUX, t_codes = 0, t_out = 0;
+    (void)t_codes;
     unsigned long long stage = 0;                       // grid stages completed in this launch
     int stamp_i = 0;
 #define MSTAMP() do { if (a.stamps && b == 0 && asub == 0 && lane == 0 && l == L0 + 1 && stamp_i < 60) a.stamps[stamp_i++] = __builtin_amdgcn_s_memrealtime(); } while (0)
