@@ -114,25 +114,24 @@ __global__ __launch_bounds__(64) void k_nucleus(const float* __restrict__ prob, 
         if (lane == 0) *seed = s;
     }
     // The walks below add 64 entries per step (one per lane, broadcast with v_readlane) in straight-line
-    // code: the running sum is the only dependency, the "first index where the condition held" is
-    // carried in selects, and there is one branch per 64 entries instead of one per entry.
+    // code.  The running sum is the only dependency chain; lane k keeps the sum as it stood after entry k,
+    // so "the first entry at which the condition held" is ONE vector compare + ballot per 64 entries.
     // sampler_mass_index (sampler.c:88-113)
     float mass = 0.0f;
     int id = n - 1;
     for (int b = 0; b < n; b += 64) {
         const float v = (b + lane < n) ? prob[b + lane] : 0.0f;      // +0 past the end: exact
-        float run = mass, at = 0.0f;
-        int first = 64;
+        float run = mass, mine = 0.0f;
 #pragma unroll
         for (int k = 0; k < 64; k++) {
             run = run + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
-            const bool c = (run > top_p) && (first == 64);
-            first = c ? k : first;
-            at = c ? run : at;
+            mine = (lane == k) ? run : mine;
         }
-        if (first < 64) {
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(mine > top_p);
+        if (hit) {
+            const int first = __builtin_ctzll(hit);
             id = b + first;
-            mass = at;
+            mass = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), first));
             break;
         }
         mass = run;
@@ -151,15 +150,15 @@ __global__ __launch_bounds__(64) void k_nucleus(const float* __restrict__ prob, 
     int pick = -1;
     for (int b = 0; b <= id; b += 64) {
         const float v = (b + lane <= id) ? prob[b + lane] : 0.0f;
-        int first = 64;
+        float mine = 0.0f;
 #pragma unroll
         for (int k = 0; k < 64; k++) {
             cdf = cdf + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
-            const bool c = (r < cdf) && (first == 64) && (b + k <= id);
-            first = c ? k : first;
+            mine = (lane == k) ? cdf : mine;
         }
-        if (first < 64) {
-            pick = b + first;
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64((r < mine) && (b + lane <= id));
+        if (hit) {
+            pick = b + __builtin_ctzll(hit);
             break;
         }
     }
