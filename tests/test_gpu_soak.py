@@ -1,0 +1,36 @@
+"""Soak (tools/soak.py in test form): graph replay == eager launches over 2,300 positions -- all three attention
+launch shapes, the in-launch ticket merge and the wide merge launch -- and a 1,500-token prompt through
+q3_prefill == token by token.  Size-independent property: every logit bit-identical."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import q3lib as Q
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graph_eager_and_prefill_agree_over_long_runs(hip):
+    path = os.path.join(Q.tmp_dir(), "soak.bin")
+    Q.synth("4Bmini", path, seq_len=4096, vocab_size=4096)
+    a = hip.q3_model_open(path.encode(), 0, 0)       # graph replay
+    b = hip.q3_model_open(path.encode(), 0, 0)       # eager: layer taps force plain launches
+    hip.q3_tap_enable(b, 1)
+    tok = 11
+    for pos in range(2300):
+        la = Q.logits_array(a, hip.forward(a, tok, pos))
+        lb = Q.logits_array(b, hip.forward(b, tok, pos))
+        assert np.array_equal(la, lb), pos
+        tok = int(la.argmax()) if pos % 7 else int((pos * 2654435761) % 4096)
+    hip.q3_model_close(b)
+    prompt = np.random.default_rng(1).integers(0, 4096, size=1500).astype(np.int32)
+    arr = (C.c_int * len(prompt))(*[int(t) for t in prompt])
+    c = hip.q3_model_open(path.encode(), 0, 0)
+    lc = Q.logits_array(c, hip.q3_prefill(c, arr, len(prompt), 0))
+    for pos, t in enumerate(prompt):                 # model `a` is reused from position 0
+        la = hip.forward(a, int(t), pos)
+    assert np.array_equal(lc, Q.logits_array(a, la))
+    hip.q3_model_close(a)
+    hip.q3_model_close(c)
