@@ -102,6 +102,14 @@ int q3_generate_greedy(Model* m, int token, int pos, int n, int* out_tokens);
  * `bytes`: the measured companion of the vendor HBM peak in bench.py. */
 double q3_measure_copy_gbps(size_t bytes, int iters);
 
+/* The token loop of the reference's completion() (src/completion.c:57-84) on token ids: prompt through
+ * q3_prefill, then device-side sampling until `max_new` tokens exist, the context window is full, or the
+ * sampler returns stop_a / stop_b (the reference: BOS / EOS; pass -1 for none; not emitted).  Same tokens
+ * and same final *seed as the reference loop with a Sampler{temperature, top_p, seed}.  Returns the number
+ * of tokens written to `out`. */
+int q3_complete(Model* m, const int* ids, int n_ids, float temperature, float top_p, uint64_t* seed, int stop_a, int stop_b,
+                int* out, int max_new);
+
 /* Batched prompt ingestion (no counterpart call in the reference, whose completion() feeds the
  * prompt through forward() one token at a time, src/completion.c:57-66): positions pos0..pos0+n-1
  * take `tokens`, 64 at a time, the Q8_0 products on the int8 matrix cores.  The KV cache and the

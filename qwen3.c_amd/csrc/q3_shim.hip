@@ -1177,6 +1177,55 @@ double q3_measure_copy_gbps(size_t bytes, int iters) {
     return 2.0 * (double)bytes * iters / ((double)ms * 1e-3) / 1e9;
 }
 
+/* The token loop of the reference's completion() (src/completion.c:57-84) without the tokenizer: the
+ * prompt ids go in through q3_prefill, then tokens are sampled on the device until `max_new` of them
+ * exist, the context window is full, or the sampler returns one of the two stop ids (the reference
+ * stops on BOS / EOS, which it does not emit).  Generation runs in blocks of up to 16 steps without
+ * a host round trip; whatever a block computed past the end is discarded, and *seed comes back
+ * advanced by exactly the draws the reference loop would have made, so the call is interchangeable
+ * with that loop for the same Sampler state.  Returns the number of tokens written to `out`. */
+int q3_complete(Model* m, const int* ids, int n_ids, float temperature, float top_p, uint64_t* seed, int stop_a, int stop_b,
+                int* out, int max_new) {
+    Dev* d = attach(m);
+    if (d->world > 1) Q3_DIE("q3_complete: single-GPU models only");
+    if (!ids || n_ids < 1 || !seed || (max_new > 0 && !out)) Q3_DIE("q3_complete: bad arguments");
+    if (n_ids > d->seq) Q3_DIE("q3_complete: prompt of %d tokens exceeds the context window %d", n_ids, d->seq);
+    // the reference checks `next` against the stop ids while it is still feeding the prompt
+    for (int k = 1; k < n_ids; k++) {
+        if (ids[k] == stop_a || ids[k] == stop_b) {
+            q3_prefill(m, ids, k, 0);
+            return 0;
+        }
+    }
+    q3_prefill(m, ids, n_ids, 0);
+    const uint64_t seed0 = *seed;
+    uint64_t sgen = seed0;               // RNG state of the candidate generator (may run ahead)
+    std::vector<int> cand;               // cand[i-1] = c_i, the i-th token the sampler returns
+    int produced = 0, i = 0;             // i = draws the reference loop has made so far
+    while (produced < max_new) {
+        if (i == (int)cand.size()) {
+            if (i == 0) {                // c_1: from the logits of the last prompt position
+                cand.push_back(q3_device_sample(m, temperature, top_p, &sgen));
+            } else {                     // feed c_i at position n_ids-1+i, and go on from there on the device
+                const int p0 = n_ids - 1 + i;
+                int block = d->seq - p0 < 16 ? d->seq - p0 : 16;
+                if (block > max_new - produced) block = max_new - produced;
+                std::vector<int> got((size_t)block);
+                q3_generate_sampled(m, cand[(size_t)i - 1], p0, block, temperature, top_p, &sgen, got.data());
+                cand.insert(cand.end(), got.begin(), got.end());
+            }
+        }
+        const int next = cand[(size_t)i++];
+        if (next == stop_a || next == stop_b) break;
+        out[produced++] = next;
+        if (n_ids - 1 + i >= d->seq) break;           // `next` would be fed beyond the window: the reference's loop bound
+    }
+    uint64_t s = seed0;
+    for (int k = 0; k < i; k++) (void)host_xorshift_float(&s);
+    *seed = s;
+    return produced;
+}
+
 void q3_kv_fill_random(Model* m, int T, uint64_t seed) {
     Dev* d = attach(m);
     if (T > d->seq) T = d->seq;

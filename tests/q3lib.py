@@ -223,6 +223,8 @@ def hip_lib():
         lib.q3_pipeline_allreduce_max.argtypes = [C.c_double]
         lib.q3_measure_copy_gbps.restype = C.c_double
         lib.q3_measure_copy_gbps.argtypes = [C.c_size_t, C.c_int]
+        lib.q3_complete.restype = C.c_int
+        lib.q3_complete.argtypes = [ModelP, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
         lib.q3_prefill.restype = c_float_p
         lib.q3_prefill.argtypes = [ModelP, C.POINTER(C.c_int), C.c_int, C.c_int]
         lib.q3_op_gemm.restype = None

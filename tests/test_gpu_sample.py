@@ -77,3 +77,57 @@ def test_sampled_decode_matches_oracle_stream(hip, host, orc, name):
     assert n == steps and list(out) == stream_g and sl.value == sg.value
     hip.q3_model_close(mg)
     host.q3_model_close(mo)
+
+
+def reference_loop(orc, mo, ids, V, seq, temperature, top_p, seed, stops, max_new):
+    """completion()'s token loop (src/completion.c:57-84) on the oracle, with the caller's cap on new tokens"""
+    state = C.c_uint64(seed)
+    out, token = [], int(ids[0])
+    for pos in range(seq):
+        lo = Q.logits_array(mo, orc.orc_forward(mo, token, pos)).copy()
+        if pos + 1 < len(ids):
+            nxt = int(ids[pos + 1])
+        else:
+            if len(out) >= max_new:
+                break
+            nxt = orc.orc_sample(Q.fptr(lo), V, temperature, top_p, C.byref(state))
+        if nxt in stops:
+            break
+        if pos + 1 >= len(ids):
+            out.append(nxt)
+        token = nxt
+    return out, state.value
+
+
+@pytest.mark.parametrize("case", ["cap", "stop", "window", "stop_in_prompt"])
+def test_complete_equals_the_reference_token_loop(hip, host, orc, case):
+    path = os.path.join(Q.tmp_dir(), "tiny.bin")
+    spec = Q.synth("tiny", path)
+    V, seq = spec.vocab_size, spec.seq_len
+    orc.orc_set_mode(Q.ORC_TREE)
+    temperature, top_p, seed = 0.9, 0.95, 777
+    prompt = [5, 17, 300, 44, 9]
+    stops, max_new = (-1, -1), 20
+    if case == "window":
+        max_new = 10 * seq                      # the context window ends the loop
+    mo = host.q3_model_open(path.encode(), 0, 1)
+    if case == "stop":                          # a token the stream is known to produce becomes the stop id
+        dry, _ = reference_loop(orc, mo, prompt, V, seq, temperature, top_p, seed, stops, 40)
+        stops = (dry[7], -1)
+        max_new = 40
+    if case == "stop_in_prompt":
+        stops = (-1, prompt[3])
+    want, want_seed = reference_loop(orc, mo, prompt, V, seq, temperature, top_p, seed, stops, max_new)
+    mg = hip.q3_model_open(path.encode(), 0, 0)
+    out = (C.c_int * (seq + 8))()
+    sg = C.c_uint64(seed)
+    arr = (C.c_int * len(prompt))(*prompt)
+    n = hip.q3_complete(mg, arr, len(prompt), temperature, top_p, C.byref(sg), stops[0], stops[1], out, min(max_new, seq + 8))
+    assert list(out[:n]) == want
+    assert sg.value == want_seed
+    if case == "stop":
+        assert n == 7
+    if case == "stop_in_prompt":
+        assert n == 0 and sg.value == seed
+    hip.q3_model_close(mg)
+    host.q3_model_close(mo)
