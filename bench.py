@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--model", default="4B")
     ap.add_argument("--context", type=int, default=0, help="cached positions before the timed steps")
     ap.add_argument("--seq-len", type=int, default=8192, help="context window allocated on the device")
+    ap.add_argument("--dtype", default="q8", choices=["q8", "fp16"],
+                    help="fp16 = the contrast path of BASELINE config 5 (weights dequantised to binary16 at attach)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -160,7 +162,7 @@ def main():
     p = m.contents.params
     vocab = p.vocab_size
     t0 = time.perf_counter()
-    assert hip.q3_device_attach(m) == 0
+    assert (hip.q3_device_attach_fp16(m) if args.dtype == "fp16" else hip.q3_device_attach(m)) == 0
     log(f"[bench] weights resident in HBM after {time.perf_counter() - t0:.1f}s")
 
     K, W = args.steps, args.warmup
@@ -217,6 +219,14 @@ def main():
     out["config"]["launch"] = ("persistent step kernel (1 launch/step)" if hip.q3_uses_persistent_kernel(m)
                                else "hipGraph of per-stage kernels")
     bpt = hip.q3_bytes_per_token(C.byref(p), pos0 + W + K // 2)
+    if args.dtype == "fp16":
+        # binary16 weights: 2 bytes per element instead of 1 + 4/64; everything else as in the Q8_0 count
+        Pd, KVD = p.n_heads * p.head_dim, p.n_kv_heads * p.head_dim
+        elems = p.n_layers * (p.dim * (Pd + 2 * KVD) + Pd * p.dim + 3 * p.dim * p.hidden_dim) + p.vocab_size * p.dim
+        bpt = bpt - elems * (1.0 + 4.0 / 64.0) + elems * 2.0
+        out["metric"] = out["metric"].replace("Q8_0", "fp16 (dequantised, contrast path)")
+        out["dtype"] = "binary16 weights x fp32 activations, fp32 accumulate"
+        out["config"]["workload"] = out["config"]["workload"].replace("random-init Q8_0 (group 64)", "random-init Q8_0 dequantised to binary16 at attach")
     per_gpu_rate = out["value"] / ngpu
     out["hbm_roofline_frac_step"] = round(per_gpu_rate * bpt / 1e9 / HBM_PEAK_GBS * (1 if ngpu == 1 else 1.0), 4)
     out["bytes_per_token"] = int(bpt)
@@ -228,7 +238,7 @@ def main():
         hip.q3_pipeline_run(m, tok, pos + 8, K); hip.q3_device_sync(m)
         out["device_loop_tokens_per_s"] = round(K / (time.perf_counter() - t0), 2)
         pos += 8 + K
-    if ngpu == 1 and pos + 600 < seq:
+    if ngpu == 1 and pos + 600 < seq and args.dtype == "q8":
         # prompt ingestion (q3_prefill: 16 positions per pass, Q8_0 products on int8 MFMA; bit-identical
         # to feeding the prompt through forward()) -- reported next to the decode rate, not part of `value`
         n_pf = 256
@@ -238,7 +248,7 @@ def main():
         hip.q3_prefill(m, prompt, n_pf, pos)
         out["prefill_tokens_per_s"] = round(n_pf / (time.perf_counter() - t0), 1)
         pos += n_pf
-    if rank == 0 and ngpu == 1 and not args.no_roofline:
+    if rank == 0 and ngpu == 1 and not args.no_roofline and args.dtype == "q8":
         # the roofline is quoted against the vendor HBM peak; next to it, what a plain device copy reaches here
         copy = hip.q3_measure_copy_gbps(1 << 30, 8)
         out["hbm_copy_gbps_measured"] = round(copy, 1)

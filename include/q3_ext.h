@@ -81,6 +81,11 @@ int q3_device_count(void);
  *   Q3_GRAPH=0|1       replay the step through a hipGraph (default 1)
  * Returns 0 on success; on failure prints the reason and returns -1. */
 int q3_device_attach(Model* m);
+/* The fp16 CONTRAST path (BASELINE config 5; nothing like it in the reference): attach with every Q8_0
+ * matrix dequantised (q*s) and rounded to binary16 on the device; forward() then runs on those weights with
+ * fp32 activations and no activation quantisation.  Must come before anything else touches the device for
+ * this Model.  q3_prefill / the pipeline are Q8_0-only. */
+int q3_device_attach_fp16(Model* m);
 void q3_device_detach(Model* m);
 void q3_device_sync(Model* m);
 /* 1 when the steps of this Model run as the persistent single-launch kernel (q3_mega.hip):

@@ -527,3 +527,96 @@ int orc_sample(float* logits, int vocab_size, float temperature, float top_p, ui
     free(dist);
     return tok;
 }
+
+/* ------------------------------------------------- fp16 contrast path ---- */
+/* BASELINE config 5: the same model with every Q8_0 matrix dequantised (q*s, the
+ * reference's q8_dequantize, src/q8.c:32-40) and rounded to IEEE binary16 at upload, activations kept
+ * in fp32 -- no q8_quantize anywhere.  There is no reference counterpart; this restatement is the
+ * checker of that path and accumulates every product in double, so the GPU's fp32 sums are compared
+ * against the best available value ("parity unpinned", tolerance in tests/test_gpu_fp16.py). */
+static float half_round(float f) {          /* to binary16 (round to nearest even) and back */
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = x & 0x80000000u;
+    uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) return f;                        /* inf / nan */
+    if (ax < 0x38800000u) {                                 /* below 2^-14: half subnormal, quantum 2^-24 */
+        float a = fabsf(f) * 16777216.0f;
+        a = rintf(a) * (1.0f / 16777216.0f);
+        return sign ? -a : a;
+    }
+    ax += 0xfffu + ((ax >> 13) & 1u);
+    ax &= ~0x1fffu;
+    if (ax >= 0x47800000u) ax = 0x7f800000u;                /* >= 65520 rounds to inf */
+    x = sign | ax;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+static void matmul_f16(float* out, const float* x, const Q8Tensor* w, int n, int d, int block_size) {
+    const int groups = n / block_size;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int i = 0; i < d; i++) {
+        const int8_t* wr = w->q + (size_t)i * n;
+        const float* ws = w->s + (size_t)i * groups;
+        double acc = 0.0;
+        for (int k = 0; k < n; k++) acc += (double)half_round((float)wr[k] * ws[k / block_size]) * (double)x[k];
+        out[i] = (float)acc;
+    }
+}
+
+static void rmsnorm_d(float* out, const float* x, const float* w, int size) {
+    double ss = 0.0;
+    for (int i = 0; i < size; i++) ss += (double)x[i] * x[i];
+    const float s = 1.0f / sqrtf((float)(ss / size) + 1e-6f);
+    for (int i = 0; i < size; i++) out[i] = w[i] * (s * x[i]);
+}
+
+/* forward() of the fp16 contrast path; needs a Model with host state; token embedding = half(q*s) */
+float* orc_forward_f16(Model* m, int token, int pos) {
+    const ModelParams* p = &m->params;
+    const ModelWeights* w = &m->weights;
+    ForwardState* s = &m->state;
+    const int dim = p->dim, hd = p->head_dim, bs = p->block_size;
+    const int kv_dim = p->n_kv_heads * hd, proj_dim = p->n_heads * hd;
+    const int old_mode = g_mode;
+    g_mode = ORC_TREE;                                       /* attention: the kernel's trees and q3_expf */
+    for (int i = 0; i < dim; i++) {
+        const size_t e = (size_t)token * dim + i;
+        s->x[i] = half_round((float)w->qe->q[e] * w->qe->s[e / bs]);
+    }
+    for (int l = 0; l < p->n_layers; l++) {
+        const size_t loff = (size_t)l * p->seq_len * kv_dim;
+        s->k = s->k_cache + loff + (size_t)pos * kv_dim;
+        s->v = s->v_cache + loff + (size_t)pos * kv_dim;
+        rmsnorm_d(s->x_rms_norm, s->x, w->att_rms_norm + (size_t)l * dim, dim);
+        matmul_f16(s->q, s->x_rms_norm, w->wq + l, dim, proj_dim, bs);
+        matmul_f16(s->k, s->x_rms_norm, w->wk + l, dim, kv_dim, bs);
+        matmul_f16(s->v, s->x_rms_norm, w->wv + l, dim, kv_dim, bs);
+        const float* gq = w->q_rms_norm + (size_t)l * hd;
+        const float* gk = w->k_rms_norm + (size_t)l * hd;
+        for (int h = 0; h < p->n_heads; h++) {
+            float* q = s->q + (size_t)h * hd;
+            orc_rmsnorm(q, q, gq, hd);
+            orc_rotary(q, hd, pos);
+        }
+        for (int h = 0; h < p->n_kv_heads; h++) {
+            float* k = s->k + (size_t)h * hd;
+            orc_rmsnorm(k, k, gk, hd);
+            orc_rotary(k, hd, pos);
+        }
+        orc_attention(m, l, pos);
+        matmul_f16(s->mlp_in, s->x_rms_norm, w->wo + l, proj_dim, dim, bs);       /* mlp_in: scratch of >= dim floats */
+        for (int i = 0; i < dim; i++) s->x[i] += s->mlp_in[i];
+        rmsnorm_d(s->x_rms_norm, s->x, w->ffn_rms_norm + (size_t)l * dim, dim);
+        matmul_f16(s->mlp_in, s->x_rms_norm, w->w1 + l, dim, p->hidden_dim, bs);
+        matmul_f16(s->mlp_gate, s->x_rms_norm, w->w3 + l, dim, p->hidden_dim, bs);
+        orc_swiglu(s->mlp_in, s->mlp_gate, p->hidden_dim);
+        matmul_f16(s->x_rms_norm, s->mlp_in, w->w2 + l, p->hidden_dim, dim, bs);
+        for (int i = 0; i < dim; i++) s->x[i] += s->x_rms_norm[i];
+    }
+    rmsnorm_d(s->x, s->x, w->out_rms_norm, dim);
+    matmul_f16(s->logits, s->x, w->cls, dim, p->vocab_size, bs);
+    g_mode = old_mode;
+    return s->logits;
+}

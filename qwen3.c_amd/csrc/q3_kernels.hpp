@@ -109,6 +109,14 @@ void gemm_q8(const int8_t* W, const float* S, int n, int d, const int8_t* xq, co
 void prefill_begin(const int* tokens, int ntok, int pos0, const int8_t* eq, const float* es, int dim, float* x, int ldx,
                    const float* rope, int hd, float* cs, Ctl* ctl, hipStream_t st);
 
+// ---- fp16 contrast path (q3_fp16.hip; BASELINE config 5) ------------------------------------
+void to_half(const int8_t* q, const float* s, size_t n, void* out, hipStream_t st);     // half(q*s)
+void embed_half(const Ctl* ctl, const void* e, int dim, float* x, hipStream_t st);
+// out (=, or += when nw is null) W x, W [d][n] binary16, x fp32 (rmsnorm'ed with weight nw when given);
+// EPI_SWIGLU: rows interleaved (gate, up) -> out[d/2].  Only the three combinations a layer uses exist:
+// (nw, STORE), (nw, SWIGLU), (null, RESID).
+void gemv_f16(const void* W, int n, int d, const float* x, const float* nw, float* out, Epi epi, hipStream_t st);
+
 // ---- device-side sampling (q3_sample.hip) -----------------------------------------------
 #define Q3_SAMPLE_MAX_CHUNKS 1024
 struct SampleBufs {

@@ -52,6 +52,7 @@
 namespace {
 
 struct LayerDev {
+    void *qkv_h = nullptr, *wo_h = nullptr, *gu_h = nullptr, *dn_h = nullptr;   // fp16 contrast path only (binary16 copies)
     int8_t *qkv_q, *wo_q, *gu_q, *dn_q;
     float *qkv_s, *wo_s, *gu_s, *dn_s;
     float *att_nw, *ffn_nw, *qnw, *knw;
@@ -76,6 +77,7 @@ struct Pipe {
 Pipe g_pipe;
 // stage identity for the next attach() (loopback self-test only); world 0 = use g_pipe
 struct NextStage { int rank = 0, world = 0; } g_next_stage;
+bool g_next_fp16 = false;       // the next attach() builds the fp16 contrast path (q3_device_attach_fp16)
 
 struct Dev {
     Model* m = nullptr;
@@ -112,6 +114,9 @@ struct Dev {
     size_t cache_floats = 0;      // floats of one stream's K (or V) cache of one layer
     std::vector<hipGraphExec_t> pgexec;   // [stream*3 + AttMode], step without the ctl upload
     int* ptokens = nullptr;       // last stage: [n_streams][cap] chosen tokens
+    // fp16 contrast path (BASELINE config 5): weights dequantised to binary16 at attach, activations fp32
+    bool fp16 = false;
+    void *emb_h = nullptr, *cls_h = nullptr;
     // batched prompt ingestion (q3_prefill.hip): buffers for one chunk of 16 positions
     bool pf_ready = false;
     int* pf_tokens = nullptr;
@@ -374,6 +379,28 @@ Dev* attach(Model* m) {
     d->use_graph = !(eg && eg[0] == '0');
 
     upload_weights(d);
+    {
+        const char* ef = getenv("Q3_FP16");
+        d->fp16 = g_next_fp16 || (ef && ef[0] == '1');
+        g_next_fp16 = false;
+        if (d->fp16) {
+            auto conv = [&](const int8_t* q, const float* sc, size_t elems) {
+                void* h = dalloc<uint16_t>(d, elems);
+                q3k::to_half(q, sc, elems, h, d->st);
+                return h;
+            };
+            const size_t QKV = (size_t)d->P + 2 * d->KVD;
+            for (int l = d->l0; l < d->l1; l++) {
+                LayerDev& L = d->layers[l];
+                L.qkv_h = conv(L.qkv_q, L.qkv_s, QKV * d->dim);
+                L.wo_h = conv(L.wo_q, L.wo_s, (size_t)d->dim * d->P);
+                L.gu_h = conv(L.gu_q, L.gu_s, (size_t)2 * d->hid * d->dim);
+                L.dn_h = conv(L.dn_q, L.dn_s, (size_t)d->dim * d->hid);
+            }
+            if (d->has_embed) d->emb_h = conv(d->emb_q, d->emb_s, (size_t)d->V * d->dim);
+            if (d->has_cls) d->cls_h = (d->cls_q == d->emb_q && d->emb_h) ? d->emb_h : conv(d->cls_q, d->cls_s, (size_t)d->V * d->dim);
+        }
+    }
     build_rope(d);
     d->x = dalloc<float>(d, d->dim + 1);      // + the token slot of pipeline messages
     d->xout = dalloc<float>(d, d->dim + 1);
@@ -516,7 +543,23 @@ q3k::Attn attn_args(Dev* d, int l, int stream = 0) {
     return a;
 }
 
+// fp16 contrast path: the same five stages on binary16 weights and fp32 activations
+void enqueue_layer_f16(Dev* d, int l, q3k::AttMode mode, int stream) {
+    const LayerDev& L = d->layers[l];
+    q3k::gemv_f16(L.qkv_h, d->dim, d->P + 2 * d->KVD, d->x, L.att_nw, d->qkv, q3k::EPI_STORE, d->st);
+    q3k::Attn a = attn_args(d, l, stream);
+    a.of = d->att_f;                     // fp32 head outputs (the codes are written too and ignored)
+    q3k::attn(a, d->chunk_slots, mode, d->st);
+    q3k::gemv_f16(L.wo_h, d->P, d->dim, d->att_f, nullptr, d->x, q3k::EPI_RESID, d->st);
+    q3k::gemv_f16(L.gu_h, d->dim, 2 * d->hid, d->x, L.ffn_nw, d->h, q3k::EPI_SWIGLU, d->st);
+    q3k::gemv_f16(L.dn_h, d->hid, d->dim, d->h, nullptr, d->x, q3k::EPI_RESID, d->st);
+}
+
 void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
+    if (d->fp16) {
+        enqueue_layer_f16(d, l, mode, stream);
+        return;
+    }
     const LayerDev& L = d->layers[l];
     q3k::Gemv g;
     memset(&g, 0, sizeof(g));
@@ -568,6 +611,10 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
 }
 
 void enqueue_head(Dev* d) {
+    if (d->fp16) {
+        q3k::gemv_f16(d->cls_h, d->dim, d->V, d->x, d->out_nw, d->logits, q3k::EPI_STORE, d->st);
+        return;
+    }
     q3k::Gemv g;
     memset(&g, 0, sizeof(g));
     g.W = d->cls_q; g.S = d->cls_s; g.n = d->dim; g.d = d->V;
@@ -586,8 +633,9 @@ void enqueue_step(Dev* d, q3k::AttMode mode, int stream = 0) {
     }
     {
         Timed t(d, "begin", 0.0);
-        q3k::begin_step(d->ctl, d->has_embed ? d->emb_q : nullptr, d->emb_s, d->dim, d->x, d->rope, d->hd,
+        q3k::begin_step(d->ctl, (d->has_embed && !d->fp16) ? d->emb_q : nullptr, d->emb_s, d->dim, d->x, d->rope, d->hd,
                         d->cs_cur, d->st);
+        if (d->fp16 && d->has_embed) q3k::embed_half(d->ctl, d->emb_h, d->dim, d->x, d->st);
     }
     for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, mode, stream);
     if (d->has_cls) enqueue_head(d);
@@ -765,6 +813,17 @@ int q3_device_count(void) {
 
 int q3_device_attach(Model* m) {
     if (!m) return -1;
+    attach(m);
+    return 0;
+}
+
+/* q3_device_attach() for the fp16 contrast path (BASELINE config 5): every Q8_0 matrix is dequantised and
+ * rounded to binary16 on the device, forward() then runs on those with fp32 activations.  Must be the
+ * first call that touches the device for this Model.  (Q3_FP16=1 in the environment does the same.) */
+int q3_device_attach_fp16(Model* m) {
+    if (!m) return -1;
+    if (lookup(m)) Q3_DIE("q3_device_attach_fp16: this Model already has device state");
+    g_next_fp16 = true;
     attach(m);
     return 0;
 }
@@ -1055,6 +1114,7 @@ void prefill_chunk(Dev* d, const int* tokens, int bc, int pos0) {
 float* q3_prefill(Model* m, const int* tokens, int n, int pos0) {
     Dev* d = attach(m);
     if (d->world > 1) Q3_DIE("q3_prefill: single-GPU models only");
+    if (d->fp16) Q3_DIE("q3_prefill: the fp16 contrast path has no batched form");
     if (!tokens || n < 1) Q3_DIE("q3_prefill: empty prompt");
     if (pos0 < 0 || pos0 + n > d->seq) Q3_DIE("q3_prefill: positions [%d,%d) outside the context window [0,%d)", pos0, pos0 + n, d->seq);
     for (int i = 0; i < n; i++) {

@@ -223,6 +223,8 @@ def hip_lib():
         lib.q3_pipeline_allreduce_max.argtypes = [C.c_double]
         lib.q3_measure_copy_gbps.restype = C.c_double
         lib.q3_measure_copy_gbps.argtypes = [C.c_size_t, C.c_int]
+        lib.q3_device_attach_fp16.restype = C.c_int
+        lib.q3_device_attach_fp16.argtypes = [ModelP]
         lib.q3_complete.restype = C.c_int
         lib.q3_complete.argtypes = [ModelP, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
         lib.q3_prefill.restype = c_float_p
@@ -276,6 +278,8 @@ def oracle_lib():
         lib.orc_forward.restype = c_float_p
         lib.orc_forward.argtypes = [ModelP, C.c_int, C.c_int]
         lib.orc_layer_step.argtypes = [ModelP, C.c_int, C.c_int, c_float_p, c_float_p]
+        lib.orc_forward_f16.restype = c_float_p
+        lib.orc_forward_f16.argtypes = [ModelP, C.c_int, C.c_int]
         lib.orc_xorshift_float.restype = C.c_float
         lib.orc_xorshift_float.argtypes = [C.POINTER(C.c_uint64)]
         lib.orc_sampler_clamp.argtypes = [c_float_p, c_float_p]
