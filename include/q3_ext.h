@@ -88,9 +88,11 @@ int q3_device_attach(Model* m);
 int q3_device_attach_fp16(Model* m);
 void q3_device_detach(Model* m);
 void q3_device_sync(Model* m);
-/* 1 when the steps of this Model run as the persistent single-launch kernel (q3_mega.hip):
- * opt-in with Q3_MEGA=1, Qwen3-4B layer shapes on a 256-CU device. */
-int q3_uses_persistent_kernel(Model* m);
+/* Which stages of a layer run fused across an in-launch hand-off between the workgroups (one
+ * launch instead of two or three; 256-CU device, layer shapes the kernels are compiled for;
+ * Q3_FUSED=0 in the environment at attach keeps one launch per stage):
+ *   bit 0  rmsnorm + gate/up + SwiGLU + down + residual (k_mlp) */
+int q3_fused_stages(Model* m);
 
 /* One decode step without the logits copy: logits stay on the device.
  * Pair with q3_logits_fetch() or q3_device_argmax(). */

@@ -37,6 +37,36 @@ struct Gemv {
 
 void gemv(const Gemv& g, Pro pro, Epi epi, hipStream_t st);
 
+// ---- stages fused across an in-launch hand-off (q3_gemv.hip: k_mlp) ---------------------
+// Arrival counters of the workgroups of a fused launch (cdna_hip_programming.md Guideline 16,
+// counter form).  One per device context, zeroed once at attach; the counters only ever count
+// up, `epoch` carries the number of completed hand-offs from launch to launch (kernel
+// arguments are frozen under graph replay, device memory is not).
+struct GridSync {
+    unsigned long long shard[8][16];     // shard = blockIdx & 7, one 128-B line each
+    unsigned long long epoch;
+    unsigned long long aborted;          // sticky: a spin gave up; later waits return at once
+    unsigned long long pad[14];
+};
+// rmsnorm + quantise + gate/up + SwiGLU (forward.c:303-321), hand-off of h between the
+// workgroups, quantise + down + residual (forward.c:326-338) in ONE launch: the down weights
+// stream in while the hand-off is in progress.
+struct Mlp {
+    const int8_t* Wg;  // gate/up rows interleaved [2*hid][dim]
+    const float* Sg;
+    const int8_t* Wd;  // down [dim][hid]
+    const float* Sd;
+    int dim, hid;
+    float* x;          // residual, in and out [dim]
+    const float* nw;   // ffn RMSNorm weight [dim]
+    float* h;          // scratch [hid]: the SwiGLU output, handed from workgroup to workgroup inside the launch
+    GridSync* sync;
+    unsigned* error;   // pinned host word, raised when a bounded spin gives up
+    unsigned long long* clk;   // profiling only: as in Gemv
+};
+bool mlp_fused_supported(int dim, int hid, int n_cus);
+void mlp_fused(const Mlp& m, hipStream_t st);
+
 struct Attn {
     const Ctl* ctl;      // pos is read on the device
     const float* qkv;    // raw projections of this step: q[P] | k[KVD] | v[KVD]
@@ -137,38 +167,5 @@ void sample_init(const SampleBufs& b, int n, hipStream_t st);
 void sample(float* logits, int n, float temperature, float top_p, float coin, unsigned long long* seed_dev,
             const SampleBufs& b, int* out, int* out2, hipStream_t st);
 
-
-// ---- persistent step kernel (q3_mega.hip) --------------------------------------------
-struct MegaSync {                        // device memory, zeroed once at attach
-    unsigned long long shard[8][16];     // arrival counters, one 128-B line each
-    unsigned long long epoch;            // grid stages completed by all earlier launches
-    unsigned int error;                  // raised when a bounded spin gave up
-    unsigned int pad[13];
-};
-struct MegaLayer {
-    const int8_t *qkv_q, *wo_q, *gu_q, *dn_q;
-    const float *qkv_s, *wo_s, *gu_s, *dn_s;
-    const float *att_nw, *ffn_nw, *qnw, *knw;
-    float *kc, *vc;                      // this stream's K / V cache of the layer
-};
-struct Mega {
-    const Ctl* ctl;
-    MegaSync* sync;
-    const MegaLayer* layers;             // device array indexed by global layer id
-    int l0, l1;                          // layers [l0, l1) run in this launch
-    const int8_t* emb_q;                 // null: the residual is already in x (later pipeline stage)
-    const float* emb_s;
-    const int8_t* cls_q;                 // null: no classifier on this stage
-    const float* cls_s;
-    const float* out_nw;
-    const float* rope;                   // [seq][hd/2][2]
-    float *x, *qkv, *att_s, *h, *logits, *part;
-    int8_t* att_q;
-    int dim, hid, H, KV, hd, P, KVD, V, seq_pad, max_chunks;
-    unsigned long long* stamps;          // diagnostics (Q3_STAMPS=1): s_memrealtime marks of workgroup 0, layer l0+1
-};
-bool mega_supported(int dim, int hid, int H, int KV, int hd, int seq_pad);
-void step(const Mega* dev, const Mega& host, hipStream_t st);
-size_t step_lds_bytes(const Mega& m);
 
 }  // namespace q3k

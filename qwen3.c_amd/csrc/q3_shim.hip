@@ -133,12 +133,10 @@ struct Dev {
     unsigned long long* seed_dev = nullptr;
     int* samp_tok = nullptr;      // device slot + pinned host copy of the sampled token
     int* samp_tok_host = nullptr;
-    // persistent step kernel (q3_mega.hip)
-    bool use_mega = false;
-    q3k::MegaSync* msync = nullptr;
-    std::vector<q3k::Mega> mega_host;      // per stream
-    std::vector<q3k::Mega*> mega_dev;
-    unsigned* merr_host = nullptr;         // pinned copy of MegaSync::error
+    // stages fused across an in-launch hand-off (q3_gemv.hip: k_mlp)
+    q3k::GridSync* gsync = nullptr;
+    unsigned* gerr_host = nullptr;         // pinned: raised by a kernel whose bounded spin gave up
+    bool fused_mlp = false;
     int ptokens_cap = 0;
     bool tap = false;
     std::vector<float> tap_host;
@@ -289,57 +287,28 @@ void pipeline_split(const ModelParams* p, int rank, int world, int* first, int* 
     q3_pipeline_layers(p, rank, world, first, count);
 }
 
-// The persistent step kernel: one launch per step instead of ~180 (q3_mega.hip).  Opt-in
-// (Q3_MEGA=1) while it is slower than the graph of per-stage kernels;
-// needs a shape it is compiled for and the 256 CUs it sizes itself to.
-void setup_mega(Dev* d) {
-    const char* e = getenv("Q3_MEGA");
-    if (!(e && e[0] == '1')) return;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, d->device));
-    if (prop.multiProcessorCount != 256) return;
-    if (!q3k::mega_supported(d->dim, d->hid, d->H, d->KV, d->hd, d->seq_pad)) return;
-    d->msync = dalloc<q3k::MegaSync>(d, 1);
-    HIPCHK(hipMemsetAsync(d->msync, 0, sizeof(q3k::MegaSync), d->st));
-    HIPCHK(hipHostMalloc((void**)&d->merr_host, sizeof(unsigned), hipHostMallocDefault));
-    *d->merr_host = 0;
-    d->mega_host.resize(d->n_streams);
-    d->mega_dev.resize(d->n_streams);
-    for (int s = 0; s < d->n_streams; s++) {
-        std::vector<q3k::MegaLayer> tab(d->L);
-        memset(tab.data(), 0, tab.size() * sizeof(q3k::MegaLayer));
-        for (int l = d->l0; l < d->l1; l++) {
-            const LayerDev& L = d->layers[l];
-            q3k::MegaLayer& t = tab[l];
-            t.qkv_q = L.qkv_q; t.wo_q = L.wo_q; t.gu_q = L.gu_q; t.dn_q = L.dn_q;
-            t.qkv_s = L.qkv_s; t.wo_s = L.wo_s; t.gu_s = L.gu_s; t.dn_s = L.dn_s;
-            t.att_nw = L.att_nw; t.ffn_nw = L.ffn_nw; t.qnw = L.qnw; t.knw = L.knw;
-            t.kc = L.kc + (size_t)s * d->cache_floats;
-            t.vc = L.vc + (size_t)s * d->cache_floats;
-        }
-        q3k::MegaLayer* dtab = upload<q3k::MegaLayer>(d, tab.data(), tab.size());
-        q3k::Mega& m = d->mega_host[s];
-        memset(&m, 0, sizeof(m));
-        m.ctl = d->ctl; m.sync = d->msync; m.layers = dtab; m.l0 = d->l0; m.l1 = d->l1;
-        m.emb_q = d->has_embed ? d->emb_q : nullptr; m.emb_s = d->emb_s;
-        m.cls_q = d->has_cls ? d->cls_q : nullptr; m.cls_s = d->cls_s; m.out_nw = d->out_nw;
-        m.rope = d->rope;
-        m.x = d->x; m.qkv = d->qkv; m.att_s = d->att_s; m.h = d->h; m.logits = d->logits; m.part = d->part;
-        m.att_q = d->att_q;
-        m.dim = d->dim; m.hid = d->hid; m.H = d->H; m.KV = d->KV; m.hd = d->hd; m.P = d->P; m.KVD = d->KVD;
-        m.V = d->V; m.seq_pad = d->seq_pad; m.max_chunks = d->max_chunks;
-        m.stamps = d->stamps;
-        if (q3k::step_lds_bytes(m) > 160 * 1024) return;      // this stage's layer table does not fit
-        d->mega_dev[s] = upload<q3k::Mega>(d, &m, 1);
-    }
-    d->use_mega = true;
+// Fused launches (stages joined by an in-launch hand-off between the workgroups): they need one
+// workgroup per CU resident at the same time, so they are used only on the full 256-CU device and
+// for the layer shapes they are compiled for; Q3_FUSED=0 keeps the one-launch-per-stage path.
+void setup_fused(Dev* d) {
+    const char* e = getenv("Q3_FUSED");
+    if (e && e[0] == '0') return;
+    if (d->fp16) return;
+    int ncu = 0;
+    HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device));
+    d->gsync = dalloc<q3k::GridSync>(d, 1);
+    HIPCHK(hipMemsetAsync(d->gsync, 0, sizeof(q3k::GridSync), d->st));
+    HIPCHK(hipHostMalloc((void**)&d->gerr_host, sizeof(unsigned), hipHostMallocDefault));
+    *d->gerr_host = 0;
+    d->fused_mlp = q3k::mlp_fused_supported(d->dim, d->hid, ncu);
 }
 
-void check_mega_error(Dev* d) {
-    if (d->use_mega && d->merr_host && *d->merr_host) {
-        Q3_DIE("the persistent step kernel gave up waiting on a hand-off (MegaSync::error = %u)", *d->merr_host);
+void check_fused_error(Dev* d) {
+    if (d->gerr_host && *d->gerr_host) {
+        Q3_DIE("a fused launch gave up waiting for its workgroups (in-launch hand-off timed out)");
     }
 }
+
 
 Dev* attach(Model* m) {
     {
@@ -436,7 +405,7 @@ Dev* attach(Model* m) {
         if (!d->logits_pinned) (void)hipGetLastError();
     }
     d->tap_host.assign((size_t)d->L * d->dim, 0.0f);
-    setup_mega(d);
+    setup_fused(d);
     HIPCHK(hipStreamSynchronize(d->st));
 
     std::lock_guard<std::mutex> lk(g_mu);
@@ -588,6 +557,15 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
         g.stamps = stamp_for("wo");
         q3k::gemv(g, q3k::PRO_Q8, q3k::EPI_RESID, d->st);
     }
+    if (d->fused_mlp) {   // forward.c:303-338 in one launch (k_mlp)
+        q3k::Mlp mm;
+        memset(&mm, 0, sizeof(mm));
+        mm.Wg = L.gu_q; mm.Sg = L.gu_s; mm.Wd = L.dn_q; mm.Sd = L.dn_s; mm.dim = d->dim; mm.hid = d->hid;
+        mm.x = d->x; mm.nw = L.ffn_nw; mm.h = d->h; mm.sync = d->gsync; mm.error = d->gerr_host;
+        Timed t(d, "mlp", q3_gemv_bytes(2 * d->hid, d->dim) + q3_gemv_bytes(d->dim, d->hid));
+        mm.clk = t.clk();
+        q3k::mlp_fused(mm, d->st);
+    } else {
     {   // rmsnorm + quantise + gate/up + SwiGLU (forward.c:303-321)
         g.W = L.gu_q; g.S = L.gu_s; g.n = d->dim; g.d = 2 * d->hid;
         g.xf = d->x; g.nw = L.ffn_nw; g.out = d->h;
@@ -603,6 +581,7 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
         g.clk = t.clk();
         g.stamps = stamp_for("down");
         q3k::gemv(g, q3k::PRO_F32, q3k::EPI_RESID, d->st);
+    }
     }
     if (d->tap) {
         HIPCHK(hipMemcpyAsync(d->tap_dev + (size_t)l * d->dim, d->x, (size_t)d->dim * 4,
@@ -626,11 +605,6 @@ void enqueue_head(Dev* d) {
 
 // everything of one step that runs on this device, between the ctl upload and the logits
 void enqueue_step(Dev* d, q3k::AttMode mode, int stream = 0) {
-    if (d->use_mega && !d->prof && !d->tap) {
-        q3k::step(d->mega_dev[stream], d->mega_host[stream], d->st);
-        HIPCHK(hipMemcpyAsync(d->merr_host, &d->msync->error, sizeof(unsigned), hipMemcpyDeviceToHost, d->st));
-        return;
-    }
     {
         Timed t(d, "begin", 0.0);
         q3k::begin_step(d->ctl, (d->has_embed && !d->fp16) ? d->emb_q : nullptr, d->emb_s, d->dim, d->x, d->rope, d->hd,
@@ -678,7 +652,7 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
         HIPCHK(hipGraphLaunch(ex, d->st));
         if (to_host) {
             HIPCHK(hipStreamSynchronize(d->st));
-            check_mega_error(d);
+            check_fused_error(d);
         }
         return;
     }
@@ -853,22 +827,22 @@ void q3_device_detach(Model* m) {
     for (void* p : d->allocs) (void)hipFree(p);
     (void)hipHostFree(d->ctl_host);
     (void)hipHostFree(d->amax_host);
-    if (d->merr_host) (void)hipHostFree(d->merr_host);
+    if (d->gerr_host) (void)hipHostFree(d->gerr_host);
     (void)hipStreamDestroy(d->st);
     delete d;
 }
 
-/* 1 when steps of this Model run as the persistent single-launch kernel */
-int q3_uses_persistent_kernel(Model* m) {
+/* which stages of a layer run fused across an in-launch hand-off: bit 0 = gate/up + down (k_mlp) */
+int q3_fused_stages(Model* m) {
     Dev* d = attach(m);
-    return d->use_mega ? 1 : 0;
+    return (d->fused_mlp ? 1 : 0);
 }
 
 void q3_device_sync(Model* m) {
     Dev* d = lookup(m);
     if (d) {
         HIPCHK(hipStreamSynchronize(d->st));
-        check_mega_error(d);
+        check_fused_error(d);
     }
 }
 
