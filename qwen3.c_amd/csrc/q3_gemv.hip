@@ -533,6 +533,14 @@ __device__ __forceinline__ void wg_barrier() {
 // during the hand-off.  Same arithmetic, same order as the two separate launches.
 constexpr int HB = 3;             // 256-blocks of h a wave may have to quantise (hid <= 16*3*256)
 
+#ifdef Q3_MLP_STAMPS
+// diagnostic build: stamps[16 * workgroup + slot] <- s_memrealtime; slots 0,1,3,4,5 by wave 0, the others by the last wave
+#define MSTAMP(slot, first) do { if (a.stamps && ((first) ? tid == 0 : tid == (int)blockDim.x - 64)) \
+    a.stamps[16 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MSTAMP(slot, first) do {} while (0)
+#endif
+
 template <int NJ, int R, int NJD>
 __global__ __launch_bounds__(1024) void k_mlp(Mlp a, int ntasks, int tw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -544,6 +552,7 @@ __global__ __launch_bounds__(1024) void k_mlp(Mlp a, int ntasks, int tw) {
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63;
     if (a.clk && tid == 0) atomicMin(a.clk, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    MSTAMP(0, true);
     int8_t* lq = reinterpret_cast<int8_t*>(smem);
     float* ls = reinterpret_cast<float*>(lq + nmax);
     float* hout = ls + ((nmax >> 6) + 3 & ~3);           // [tw * R/2] SwiGLU outputs of this workgroup
@@ -568,6 +577,7 @@ __global__ __launch_bounds__(1024) void k_mlp(Mlp a, int ntasks, int tw) {
     if (uwave < nn) {
         prepare_activation<PRO_NORM>(g1, uwave, nn, lane, lq, ls);
         wg_barrier();
+        MSTAMP(1, true);
     } else {
         const int task = (sw < tcount) ? tfirst + sw : ntasks;
         const int row0 = task * R;
@@ -618,8 +628,10 @@ __global__ __launch_bounds__(1024) void k_mlp(Mlp a, int ntasks, int tw) {
 #pragma unroll
         for (int jd = (PRE < NJD ? PRE : NJD); jd < NJD; jd++) tile_issue_one<1, NJD>(TD, wdn, tln, drow, 0, jd);
         __builtin_amdgcn_sched_barrier(0);
+        MSTAMP(2, false);
     }
     wg_barrier();                                        // hout complete
+    MSTAMP(3, true);
 
     // ---- hand-off: publish this workgroup's slice of h, arrive, wait for everybody ----
     unsigned long long done = 0;                         // wave 0: hand-offs completed before this launch
@@ -634,10 +646,13 @@ __global__ __launch_bounds__(1024) void k_mlp(Mlp a, int ntasks, int tw) {
             __hip_atomic_store((__attribute__((address_space(1))) float*)(a.h + i), hout[lane], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MSTAMP(4, true);
         if (lane == 0) grid_arrive(a.sync);
         grid_wait(a.sync, done, lane, a.error);
+        MSTAMP(5, true);
     }
     wg_barrier();
+    MSTAMP(6, false);
 
     // ---- q8_quantize of h: every wave fetches (sc1) and quantises its own 256-blocks ----
     {
@@ -663,7 +678,9 @@ __global__ __launch_bounds__(1024) void k_mlp(Mlp a, int ntasks, int tw) {
             }
         }
     }
+    MSTAMP(7, false);
     wg_barrier();
+    MSTAMP(8, false);
 
     // ---- down + residual: the row this wave has been holding since the end of its gate/up tile ----
     if (sw >= 0) {
@@ -671,6 +688,7 @@ __global__ __launch_bounds__(1024) void k_mlp(Mlp a, int ntasks, int tw) {
         tile_dot<1, NJD>(TD, hid, lane, lq, ls, accd);
         if (has_down && lane == 0) a.x[drow] = res + accd[0];
     }
+    MSTAMP(9, false);
     if (b == 0 && tid == 0) a.sync->epoch = done + 1ull;
     if (a.clk) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -63,6 +63,7 @@ struct Mlp {
     GridSync* sync;
     unsigned* error;   // pinned host word, raised when a bounded spin gives up
     unsigned long long* clk;   // profiling only: as in Gemv
+    unsigned long long* stamps;   // diagnostic builds only (-DQ3_MLP_STAMPS): [16 * workgroup + slot]
 };
 bool mlp_fused_supported(int dim, int hid, int n_cus);
 void mlp_fused(const Mlp& m, hipStream_t st);

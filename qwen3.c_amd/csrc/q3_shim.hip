@@ -396,7 +396,7 @@ Dev* attach(Model* m) {
         for (int i = 0; i < 2; i++) d->outbox[i] = dalloc<float>(d, d->dim + 1);
     }
     d->pgexec.assign((size_t)d->n_streams * 3, nullptr);
-    if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 2048); HIPCHK(hipMemset(d->stamps, 0, 2048 * 8)); }
+    if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 4096); HIPCHK(hipMemset(d->stamps, 0, 4096 * 8)); }
     HIPCHK(hipHostMalloc((void**)&d->ctl_host, sizeof(q3k::Ctl), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&d->amax_host, sizeof(int), hipHostMallocDefault));
     if (m->state.logits) {
@@ -564,6 +564,7 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
         mm.x = d->x; mm.nw = L.ffn_nw; mm.h = d->h; mm.sync = d->gsync; mm.error = d->gerr_host;
         Timed t(d, "mlp", q3_gemv_bytes(2 * d->hid, d->dim) + q3_gemv_bytes(d->dim, d->hid));
         mm.clk = t.clk();
+        mm.stamps = stamp_for("mlp");
         q3k::mlp_fused(mm, d->st);
     } else {
     {   // rmsnorm + quantise + gate/up + SwiGLU (forward.c:303-321)
@@ -729,8 +730,8 @@ int q3_debug_stamps(Model* m, unsigned long long* out, int n) {
     Dev* d = lookup(m);
     if (!d || !d->stamps) return 0;
     HIPCHK(hipStreamSynchronize(d->st));
-    HIPCHK(hipMemcpy(out, d->stamps, (size_t)(n < 2048 ? n : 2048) * 8, hipMemcpyDeviceToHost));
-    return n < 2048 ? n : 2048;
+    HIPCHK(hipMemcpy(out, d->stamps, (size_t)(n < 4096 ? n : 4096) * 8, hipMemcpyDeviceToHost));
+    return n < 4096 ? n : 4096;
 }
 
 // diagnostic: `iters` back-to-back launches of one GEMV class cycling over layers [l_lo, l_hi),

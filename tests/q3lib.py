@@ -341,8 +341,16 @@ def synth(name, path, seed=None, **overrides):
     for k, v in overrides.items():
         setattr(spec, k, v)
     want = lib.q3_synth_bytes(C.byref(spec))
-    if not (os.path.exists(path) and os.path.getsize(path) == want):
+    # the cached file is reused only for the very same spec (size alone does not tell seeds apart)
+    key = repr([(n, getattr(spec, n)) for n, _ in SynthSpec._fields_])
+    side = path + ".spec"
+    same = os.path.exists(side) and open(side).read() == key
+    if not (same and os.path.exists(path) and os.path.getsize(path) == want):
+        if os.path.exists(side):
+            os.remove(side)
         assert lib.q3_synth_write(path.encode(), C.byref(spec)) == 0
+        with open(side, "w") as f:
+            f.write(key)
     return spec
 
 
@@ -356,3 +364,19 @@ def tmp_dir():
     d = os.environ.get("Q3_TMP", "/tmp/q3")
     os.makedirs(d, exist_ok=True)
     return d
+
+
+def record_parity(key, values):
+    """Merge one entry of measured parity figures into the JSON the GPU runs leave under
+    gpurun_out/ (copied to profiles/parity_rNN.json, tracked, after the run)."""
+    import json
+    path = os.environ.get("Q3_PARITY_JSON") or os.path.join(ROOT, "gpurun_out", "parity.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        doc = json.load(open(path))
+    except Exception:
+        doc = {}
+    doc[key] = values
+    with open(path + ".tmp", "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+    os.replace(path + ".tmp", path)

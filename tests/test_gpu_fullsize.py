@@ -67,8 +67,105 @@ def test_06b_against_the_reference_build_and_its_self_noise(hip):
     self_noise = float((np.abs(noisy - golden).max(axis=1) / scale).max())
     gpu_err = float((np.abs(gpu - golden).max(axis=1) / scale).max())
     print(f"0.6B: GPU vs golden {gpu_err:.3e}; reference 16 threads vs golden {self_noise:.3e}")
+    Q.record_parity("0.6B_vs_reference_build", {"positions": len(feed), "gpu_vs_golden_rel": gpu_err,
+                                               "reference_16_threads_vs_golden_rel": self_noise,
+                                               "argmax_disagreements": int(sum(gpu[p].argmax() != golden[p].argmax() for p in range(len(feed))))})
     assert gpu_err <= max(1e-3, 1.5 * self_noise)
     for p in range(len(feed)):
         if gpu[p].argmax() != golden[p].argmax():
             top2 = np.sort(golden[p])[-2:]
             assert (top2[1] - top2[0]) <= 2 * max(self_noise, gpu_err) * scale[p]
+
+
+def _tier_c_prime(hip, name, positions, seq=64):
+    """GPU vs the REAL reference build (1 thread = golden) next to the reference's own
+    self-noise (same code, 16 threads)."""
+    ref = Q.reference_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref not available")
+    gomp = C.CDLL("libgomp.so.1")
+    path = os.path.join(Q.tmp_dir(), f"{name}.bin")
+    Q.synth(name, path)
+    feed = np.random.default_rng(19).integers(0, 151936, size=positions)
+
+    def run_ref(threads):
+        gomp.omp_set_num_threads(threads)
+        m = ref.model_create(path.encode(), seq)
+        rows = [Q.logits_array(m, ref.forward(m, int(t), p)) for p, t in enumerate(feed)]
+        ref.model_free(m)
+        gomp.omp_set_num_threads(1)
+        return np.stack(rows)
+
+    golden = run_ref(1)
+    noisy = run_ref(16)
+    mg = hip.q3_model_open(path.encode(), seq, 0)
+    gpu = np.stack([Q.logits_array(mg, hip.forward(mg, int(t), p)) for p, t in enumerate(feed)])
+    hip.q3_model_close(mg)
+    scale = np.abs(golden).max(axis=1)
+    self_noise = float((np.abs(noisy - golden).max(axis=1) / scale).max())
+    gpu_err = float((np.abs(gpu - golden).max(axis=1) / scale).max())
+    flips = int(sum(gpu[p].argmax() != golden[p].argmax() for p in range(positions)))
+    Q.record_parity(f"{name}_vs_reference_build", {"positions": positions, "gpu_vs_golden_rel": gpu_err,
+                                                  "reference_16_threads_vs_golden_rel": self_noise,
+                                                  "argmax_disagreements": flips})
+    assert gpu_err <= max(1e-3, 1.5 * self_noise)
+    for p in range(positions):
+        if gpu[p].argmax() != golden[p].argmax():
+            top2 = np.sort(golden[p])[-2:]
+            assert (top2[1] - top2[0]) <= 2 * max(self_noise, gpu_err) * scale[p]
+
+
+def test_4b_against_the_reference_build_and_its_self_noise(hip):
+    """tier C' on the headline configuration (round-1 VERDICT: only 0.6B had met the real reference)"""
+    _tier_c_prime(hip, "4B", 6)
+
+
+@pytest.mark.parametrize("name", ["1.7B", "8B"])
+def test_full_size_configs_bit_exact_vs_tree_oracle(hip, host, orc, name):
+    """BASELINE configs 2 (1.7B) and 4 (8B, untied classifier) at full width: the looping classifier
+    kernel k_gemv2 at n = 2048 (NJ = 2) and n = 4096 (NJ = 4) over d = 151,936 rows, and every layer
+    kernel of those shapes, against the oracle's tree order, bit for bit."""
+    path = os.path.join(Q.tmp_dir(), f"{name}.bin")
+    Q.synth(name, path)
+    mg = hip.q3_model_open(path.encode(), 64, 0)
+    mo = host.q3_model_open(path.encode(), 64, 1)
+    orc.orc_set_mode(Q.ORC_TREE)
+    orc.orc_set_threads(16)
+    feed = np.random.default_rng(23).integers(0, 151936, size=4)
+    worst = 0.0
+    for pos, tok in enumerate(feed):
+        a = Q.logits_array(mg, hip.forward(mg, int(tok), pos))
+        b = Q.logits_array(mo, orc.orc_forward(mo, int(tok), pos))
+        assert np.isfinite(a).all()
+        worst = max(worst, float(np.abs(a - b).max()))
+        assert np.array_equal(a, b), f"{name} pos {pos}: max diff {np.abs(a - b).max()}"
+    orc.orc_set_threads(1)
+    Q.record_parity(f"{name}_vs_tree_oracle", {"positions": len(feed), "max_abs_diff": worst, "bit_exact": True})
+    hip.q3_model_close(mg); host.q3_model_close(mo)
+
+
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_classifier_loop_kernel_at_full_vocabulary(hip, orc, n):
+    """k_gemv2 (the looping GEMV) with d = 151,936 at the 1.7B / 8B widths, op level: fused rmsnorm +
+    quantise feeding the exported matmul path, vs orc_matmul in tree order (bit-exact) and reference
+    order (1e-6)."""
+    d = 151936
+    rng = np.random.default_rng(n)
+    wq = rng.integers(-127, 128, size=(d, n), dtype=np.int8)
+    ws = (rng.random((d, n // 64), dtype=np.float32) * 0.5 + 0.75) * np.float32(0.02 / 73.3)
+    xq = rng.integers(-127, 128, size=n, dtype=np.int8)
+    xs = (rng.random(n // 64, dtype=np.float32) + 0.5) * np.float32(1.0 / 127.0)
+    out = np.zeros(d, np.float32)
+    hip.q3_op_gemv(Q.i8ptr(wq), Q.fptr(ws), Q.i8ptr(xq), Q.fptr(xs), n, d, Q.fptr(out))
+    xt, wt = Q.q8view(xq, xs), Q.q8view(wq.reshape(-1), ws.reshape(-1))
+    tree = np.zeros(d, np.float32); refo = np.zeros(d, np.float32)
+    orc.orc_set_threads(16)
+    orc.orc_set_mode(Q.ORC_TREE)
+    orc.orc_matmul(Q.fptr(tree), C.byref(xt), C.byref(wt), n, d, 64)
+    orc.orc_set_mode(Q.ORC_REF)
+    orc.orc_matmul(Q.fptr(refo), C.byref(xt), C.byref(wt), n, d, 64)
+    orc.orc_set_threads(1)
+    rel = float(np.abs(out - refo).max() / np.abs(refo).max())
+    Q.record_parity(f"classifier_gemv_n{n}_d{d}", {"bit_exact_vs_tree": bool(np.array_equal(out, tree)), "rel_vs_reference_order": rel})
+    assert np.array_equal(out, tree)
+    assert rel <= 1e-6

@@ -34,3 +34,30 @@ def test_graph_eager_and_prefill_agree_over_long_runs(hip):
     assert np.array_equal(lc, Q.logits_array(a, la))
     hip.q3_model_close(a)
     hip.q3_model_close(c)
+
+
+def test_decode_meets_the_oracle_past_1100_positions(hip, host, orc):
+    """End to end against the ORACLE (not the GPU against itself) through all three attention launch
+    shapes: one chunk, in-launch merge (64..1023) and the wide merge launch (>= 1024 positions), on the
+    Qwen3-4B layer shapes: logits bit-identical to the tree-order oracle at every compared position."""
+    import numpy as np
+    path = os.path.join(Q.tmp_dir(), "4Bmini_long.bin")
+    Q.synth("4Bmini", path, seq_len=1280)
+    mg = hip.q3_model_open(path.encode(), 1280, 0)
+    mo = host.q3_model_open(path.encode(), 1280, 1)
+    orc.orc_set_mode(Q.ORC_TREE)
+    orc.orc_set_threads(16)
+    n = 1180
+    feed = np.random.default_rng(31).integers(0, 8192, size=n)
+    compared = 0
+    for pos, tok in enumerate(feed):
+        lg = hip.forward(mg, int(tok), pos)
+        lo = orc.orc_forward(mo, int(tok), pos)
+        if pos % 16 == 0 or pos in (63, 64, 65, 1023, 1024, 1025) or pos >= n - 8:
+            a = Q.logits_array(mg, lg); b = Q.logits_array(mo, lo)
+            assert np.array_equal(a, b), f"pos {pos}: max diff {np.abs(a - b).max()}"
+            compared += 1
+    orc.orc_set_threads(1)
+    Q.record_parity("4Bmini_decode_vs_tree_oracle_long", {"positions": n, "compared": compared, "bit_exact": True,
+                                                          "attention_shapes": ["single", "merge", "long"]})
+    hip.q3_model_close(mg); host.q3_model_close(mo)
