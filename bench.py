@@ -218,7 +218,8 @@ def main():
     }
     fused = hip.q3_fused_stages(m)
     out["config"]["launch"] = "hipGraph of per-stage kernels" + (
-        "; gate/up + down fused across an in-launch hand-off (k_mlp)" if fused & 1 else "")
+        "; gate/up + down fused across an in-launch hand-off (k_mlp)" if fused & 1 else "") + (
+        "; weight-streaming engine: Wo + gate/up + down + next QKV per launch (LDS-DMA ring, sentinel hand-offs)" if fused & 2 else "")
     bpt = hip.q3_bytes_per_token(C.byref(p), pos0 + W + K // 2)
     if args.dtype == "fp16":
         # binary16 weights: 2 bytes per element instead of 1 + 4/64; everything else as in the Q8_0 count

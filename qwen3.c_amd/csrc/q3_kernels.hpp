@@ -68,6 +68,29 @@ struct Mlp {
 bool mlp_fused_supported(int dim, int hid, int n_cus);
 void mlp_fused(const Mlp& m, hipStream_t st);
 
+// ---- the weight-streaming engine (q3_engine.hip): Wo, gate/up, down and the next layer's
+// Wq|Wk|Wv as one launch, weights through an LDS ring fed by LDS-DMA, hand-offs between the
+// workgroups by sentinel-tagged write-through stores ------------------------------------
+#define Q3_ENG_SENTINEL 0x7fc0deadu      // "not yet written": a NaN no arithmetic of the step produces
+struct Engine {
+    const int8_t *wo_q, *gu_q, *dn_q, *qkv_q;     // this layer's Wo, gate/up (interleaved), down; next layer's Wq|Wk|Wv (null: none)
+    const float *wo_s, *gu_s, *dn_s, *qkv_s;
+    const float* ffn_nw;        // this layer's ffn RMSNorm weight
+    const float* att_nw_next;   // next layer's attention RMSNorm weight (with qkv_q)
+    const int8_t* att_q;        // attention output codes [P] and scales [P/64] (plain memory, previous launch)
+    const float* att_s;
+    float* x;                   // residual [dim]: in (entering Wo) and out (after down), plain memory
+    float* qkv;                 // out: next layer's raw projections [P + 2 KVD], plain memory
+    float *xw, *hv, *xd;        // hand-off vectors, two sets each: [2][dim], [2][hid], [2][dim]; sentinel-poisoned
+    GridSync* sync;             // epoch (launch parity) and the sticky abort flag
+    unsigned* error;            // pinned host word
+    unsigned long long* clk;    // profiling only
+};
+bool engine_supported(int dim, int hid, int H, int KV, int hd, int n_cus);
+size_t engine_lds_bytes();
+void engine_layer(const Engine& e, hipStream_t st);
+void engine_poison(float* p, size_t n, hipStream_t st);
+
 struct Attn {
     const Ctl* ctl;      // pos is read on the device
     const float* qkv;    // raw projections of this step: q[P] | k[KVD] | v[KVD]

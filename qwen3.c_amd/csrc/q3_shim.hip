@@ -137,6 +137,10 @@ struct Dev {
     q3k::GridSync* gsync = nullptr;
     unsigned* gerr_host = nullptr;         // pinned: raised by a kernel whose bounded spin gave up
     bool fused_mlp = false;
+    // weight-streaming engine (q3_engine.hip): Wo .. next layer's QKV as one launch per layer
+    bool use_engine = false;
+    q3k::GridSync* esync = nullptr;
+    float *eng_xw = nullptr, *eng_hv = nullptr, *eng_xd = nullptr;
     int ptokens_cap = 0;
     bool tap = false;
     std::vector<float> tap_host;
@@ -301,6 +305,19 @@ void setup_fused(Dev* d) {
     HIPCHK(hipHostMalloc((void**)&d->gerr_host, sizeof(unsigned), hipHostMallocDefault));
     *d->gerr_host = 0;
     d->fused_mlp = q3k::mlp_fused_supported(d->dim, d->hid, ncu);
+    const char* ee = getenv("Q3_ENGINE");
+    if (!(ee && ee[0] == '0') && q3k::engine_supported(d->dim, d->hid, d->H, d->KV, d->hd, ncu)) {
+        d->esync = dalloc<q3k::GridSync>(d, 1);
+        HIPCHK(hipMemsetAsync(d->esync, 0, sizeof(q3k::GridSync), d->st));
+        d->eng_xw = dalloc<float>(d, 2 * (size_t)d->dim);
+        d->eng_hv = dalloc<float>(d, 2 * (size_t)d->hid);
+        d->eng_xd = dalloc<float>(d, 2 * (size_t)d->dim);
+        q3k::engine_poison(d->eng_xw, 2 * (size_t)d->dim, d->st);
+        q3k::engine_poison(d->eng_hv, 2 * (size_t)d->hid, d->st);
+        q3k::engine_poison(d->eng_xd, 2 * (size_t)d->dim, d->st);
+        d->use_engine = true;
+        d->fused_mlp = false;      // the engine covers those stages
+    }
 }
 
 void check_fused_error(Dev* d) {
@@ -612,7 +629,52 @@ void enqueue_step(Dev* d, q3k::AttMode mode, int stream = 0) {
                         d->cs_cur, d->st);
         if (d->fp16 && d->has_embed) q3k::embed_half(d->ctl, d->emb_h, d->dim, d->x, d->st);
     }
-    for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, mode, stream);
+    if (d->use_engine && d->l1 > d->l0) {
+        // QKV of the first layer as its own launch; then per layer the attention launch and ONE engine
+        // launch: Wo, gate/up, down and the NEXT layer's QKV (q3_engine.hip)
+        {
+            const LayerDev& L = d->layers[d->l0];
+            q3k::Gemv g;
+            memset(&g, 0, sizeof(g));
+            g.W = L.qkv_q; g.S = L.qkv_s; g.n = d->dim; g.d = d->P + 2 * d->KVD;
+            g.xf = d->x; g.nw = L.att_nw; g.out = d->qkv;
+            Timed t(d, "qkv", q3_gemv_bytes(g.d, g.n));
+            g.clk = t.clk();
+            q3k::gemv(g, q3k::PRO_NORM, q3k::EPI_STORE, d->st);
+        }
+        for (int l = d->l0; l < d->l1; l++) {
+            const LayerDev& L = d->layers[l];
+            {
+                q3k::Attn a = attn_args(d, l, stream);
+                Timed t(d, "attn", 0.0);
+                q3k::attn(a, d->chunk_slots, mode, d->st);
+            }
+            const bool more = l + 1 < d->l1;
+            q3k::Engine e;
+            memset(&e, 0, sizeof(e));
+            e.wo_q = L.wo_q; e.wo_s = L.wo_s; e.gu_q = L.gu_q; e.gu_s = L.gu_s; e.dn_q = L.dn_q; e.dn_s = L.dn_s;
+            e.ffn_nw = L.ffn_nw;
+            if (more) {
+                const LayerDev& N = d->layers[l + 1];
+                e.qkv_q = N.qkv_q; e.qkv_s = N.qkv_s; e.att_nw_next = N.att_nw;
+            }
+            e.att_q = d->att_q; e.att_s = d->att_s; e.x = d->x; e.qkv = d->qkv;
+            e.xw = d->eng_xw; e.hv = d->eng_hv; e.xd = d->eng_xd; e.sync = d->esync; e.error = d->gerr_host;
+            double bytes = q3_gemv_bytes(d->dim, d->P) + q3_gemv_bytes(2 * d->hid, d->dim) + q3_gemv_bytes(d->dim, d->hid);
+            if (more) bytes += q3_gemv_bytes(d->P + 2 * d->KVD, d->dim);
+            {
+                Timed t(d, more ? "engine" : "engine_last", bytes);
+                e.clk = t.clk();
+                q3k::engine_layer(e, d->st);
+            }
+            if (d->tap) {
+                HIPCHK(hipMemcpyAsync(d->tap_dev + (size_t)l * d->dim, d->x, (size_t)d->dim * 4,
+                                      hipMemcpyDeviceToDevice, d->st));
+            }
+        }
+    } else {
+        for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, mode, stream);
+    }
     if (d->has_cls) enqueue_head(d);
 }
 
@@ -836,7 +898,7 @@ void q3_device_detach(Model* m) {
 /* which stages of a layer run fused across an in-launch hand-off: bit 0 = gate/up + down (k_mlp) */
 int q3_fused_stages(Model* m) {
     Dev* d = attach(m);
-    return (d->fused_mlp ? 1 : 0);
+    return (d->fused_mlp ? 1 : 0) | (d->use_engine ? 2 : 0);
 }
 
 void q3_device_sync(Model* m) {

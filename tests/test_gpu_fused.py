@@ -20,20 +20,25 @@ def fixture_path():
     return path
 
 
-def open_with(hip, path, fused, seq=256):
-    os.environ["Q3_FUSED"] = "1" if fused else "0"
+MODES = {"plain": ("0", "0", 0), "mlp": ("1", "0", 1), "engine": ("1", "1", 2)}
+
+
+def open_with(hip, path, mode, seq=256):
+    fused, engine, want = MODES[mode]
+    os.environ["Q3_FUSED"] = fused
+    os.environ["Q3_ENGINE"] = engine
     m = hip.q3_model_open(path.encode(), seq, 0)
     assert hip.q3_device_attach(m) == 0
-    os.environ.pop("Q3_FUSED")
-    got = hip.q3_fused_stages(m)
-    assert (got != 0) == bool(fused), got
+    os.environ.pop("Q3_FUSED"); os.environ.pop("Q3_ENGINE")
+    assert hip.q3_fused_stages(m) == want, (mode, hip.q3_fused_stages(m))
     return m
 
 
-def test_fused_matches_unfused_and_oracle(hip, host, orc):
+@pytest.mark.parametrize("mode", ["mlp", "engine"])
+def test_fused_matches_unfused_and_oracle(hip, host, orc, mode):
     path = fixture_path()
-    mf = open_with(hip, path, True)
-    mk = open_with(hip, path, False)
+    mf = open_with(hip, path, mode)
+    mk = open_with(hip, path, "plain")
     mo = host.q3_model_open(path.encode(), 256, 1)
     orc.orc_set_mode(Q.ORC_TREE)
     orc.orc_set_threads(8)
@@ -41,20 +46,21 @@ def test_fused_matches_unfused_and_oracle(hip, host, orc):
     for pos, tok in enumerate(feed):
         a = Q.logits_array(mf, hip.forward(mf, int(tok), pos))
         b = Q.logits_array(mk, hip.forward(mk, int(tok), pos))
-        assert np.array_equal(a, b), f"fused vs one launch per stage at pos {pos}: {np.abs(a - b).max()}"
+        assert np.array_equal(a, b), f"{mode} vs one launch per stage at pos {pos}: {np.abs(a - b).max()}"
         if pos < 6 or 60 <= pos < 70 or pos >= 136:
             c = Q.logits_array(mo, orc.orc_forward(mo, int(tok), pos))
-            assert np.array_equal(a, c), f"fused vs oracle at pos {pos}"
+            assert np.array_equal(a, c), f"{mode} vs oracle at pos {pos}"
         elif pos < 136:
             orc.orc_forward(mo, int(tok), pos)      # keep the oracle's KV cache in step
     orc.orc_set_threads(1)
     hip.q3_model_close(mf); hip.q3_model_close(mk); host.q3_model_close(mo)
 
 
-def test_fused_layer_taps_match_oracle(hip, host, orc):
+@pytest.mark.parametrize("mode", ["mlp", "engine"])
+def test_fused_layer_taps_match_oracle(hip, host, orc, mode):
     """the eager (non-graph) launch path of the fused kernels, residual after every layer"""
     path = fixture_path()
-    mf = open_with(hip, path, True)
+    mf = open_with(hip, path, mode)
     mo = host.q3_model_open(path.encode(), 256, 1)
     orc.orc_set_mode(Q.ORC_TREE)
     L, dim = mf.contents.params.n_layers, mf.contents.params.dim
@@ -71,21 +77,23 @@ def test_fused_layer_taps_match_oracle(hip, host, orc):
     hip.q3_model_close(mf); host.q3_model_close(mo)
 
 
-def test_fused_greedy_loop_and_pipeline_stages(hip):
+@pytest.mark.parametrize("mode", ["mlp", "engine"])
+def test_fused_greedy_loop_and_pipeline_stages(hip, mode):
     path = fixture_path()
-    os.environ["Q3_FUSED"] = "0"
-    mk = hip.q3_model_open(path.encode(), 256, 0)
     n = 72
+    mk = open_with(hip, path, "plain")
     want = (C.c_int * n)()
     assert hip.q3_generate_greedy(mk, 11, 0, n, want) == n
     hip.q3_model_close(mk)
-    os.environ["Q3_FUSED"] = "1"
-    mf = hip.q3_model_open(path.encode(), 256, 0)
+    mf = open_with(hip, path, mode)
     got = (C.c_int * n)()
     assert hip.q3_generate_greedy(mf, 11, 0, n, got) == n
     hip.q3_model_close(mf)
     assert list(got) == list(want)
     st = (C.c_int * (2 * n))()
-    assert hip.q3_pipeline_selftest(path.encode(), 256, 2, 11, 0, n, st) == 0
-    os.environ.pop("Q3_FUSED")
+    os.environ["Q3_FUSED"], os.environ["Q3_ENGINE"] = MODES[mode][0], MODES[mode][1]
+    try:
+        assert hip.q3_pipeline_selftest(path.encode(), 256, 2, 11, 0, n, st) == 0
+    finally:
+        os.environ.pop("Q3_FUSED"); os.environ.pop("Q3_ENGINE")
     assert list(st[:n]) == list(want) and list(st[n:]) == list(want)
