@@ -47,16 +47,22 @@ namespace q3k {
 #define ENG_NWG 256
 #define ENG_WAVES 16
 #define ENG_CW (ENG_WAVES - 1)          // consumer waves
-#define ENG_NS 8                        // ring slots
-#define ENG_SLOT 16384
-#define ENG_SCALES_OFF 15360            // scales of a slot's rows sit behind 15 KiB of codes
 #define ENG_INFLIGHT 2                  // slots in flight beyond the one being published
 #define ENG_TIMEOUT_TICKS 200000000ull  // 2 s of the 100 MHz clock
+#define ENG_LDS_TOTAL 163840
 
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) unsigned ge_u32;
 typedef __attribute__((address_space(1))) unsigned long long ge_u64;
+
+#ifdef Q3_ENG_STAMPS
+// diagnostic build: stamps[64 * workgroup + slot] <- s_memrealtime.  [0,16) consumer 0, [16,32) consumer 14, [32,64) loader (issue of stream slot s)
+#define ESTAMP(a_, base_, i_) do { if ((a_).stamps && lane == 0) (a_).stamps[64 * blockIdx.x + (base_) + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ESTAMP(a_, base_, i_) do {} while (0)
+#endif
+#define CSTAMP(i_) do { if (cw == 0) ESTAMP(a, 0, i_); else if (cw == ENG_CW - 1) ESTAMP(a, 16, i_); } while (0)
 
 // control words in LDS
 struct EngCtl {
@@ -65,10 +71,16 @@ struct EngCtl {
     unsigned abort;           // anybody -> all: leave
     unsigned pad0;
     unsigned prog[16];        // consumer cw -> loader: first slot this wave may still read
+    unsigned hold[4];         // consumers -> loader: hold[t] = waves polling for the activation of stage t right now
+    unsigned pad[8];
 };
 
 // ---- shape of the streamed stages (Qwen3-4B) ------------------------------------------
-// Stage s of a launch: rows of width n, RW rows per workgroup, RS rows per slot.
+// A SLOT is RS rows of one matrix: their codes (rows*n bytes, in 1-KiB DMA pieces) followed, at the
+// next 1-KiB boundary, by their scales.  The ring is a byte ring: slot s sits at TAB.pos[s]; it
+// may be (re)filled once every consumer is past slot TAB.need[s], the youngest earlier slot that
+// overlaps its bytes.  Both tables are compile-time constants of the launch's slot list.
+constexpr int eng_pieces(int rows, int n) { return (rows * n + 1023) / 1024; }
 struct Cfg4B {
     static constexpr int DIM = 2560, HID = 9728, P = 4096, QKV = 6144;
     static constexpr int NJ_X = 3, NJ_P = 4, NJ_H = 10;                 // wave-loads per row
@@ -77,7 +89,43 @@ struct Cfg4B {
     static constexpr int RW_D = 10, RS_D = 1, NS_D = 10;                // down
     static constexpr int RW_Q = 24, RS_Q = 6, NS_Q = 4;                 // Wq|Wk|Wv of the next layer
     static constexpr int S0_W = 0, S0_G = NS_W, S0_D = S0_G + NS_G, S0_Q = S0_D + NS_D, S_END = S0_Q + NS_Q;
+    static constexpr int SOFF_W = eng_pieces(RS_W, P) * 1024, SOFF_G = eng_pieces(RS_G, DIM) * 1024;
+    static constexpr int SOFF_D = eng_pieces(RS_D, HID) * 1024, SOFF_Q = eng_pieces(RS_Q, DIM) * 1024;
+    static constexpr int SZ_W = SOFF_W + 1024, SZ_G = SOFF_G + 1024, SZ_D = SOFF_D + 1024, SZ_Q = SOFF_Q + 1024;
+    // LDS: [ring][R1: fp32 x of the norm stages / codes of the Wo and down stages][R2: codes of the norm
+    //       stages][scales][1 KiB dump for the DMA pieces that move nothing][control]
+    static constexpr int R1 = (DIM * 4 > HID ? DIM * 4 : HID), R2 = DIM, R3 = ((HID / 64 + 3) & ~3) * 4;
+    static constexpr int RING = (ENG_LDS_TOTAL - R1 - R2 - R3 - 1024 - (int)sizeof(EngCtl)) / 1024 * 1024;
+    static constexpr int OFF_R1 = RING, OFF_R2 = OFF_R1 + R1, OFF_R3 = OFF_R2 + R2, OFF_DUMP = OFF_R3 + R3, OFF_CTL = OFF_DUMP + 1024;
+    static constexpr int LDS_BYTES = OFF_CTL + (int)sizeof(EngCtl);
+    static constexpr int stage_of(int s) { return s < S0_G ? 0 : (s < S0_D ? 1 : (s < S0_Q ? 2 : 3)); }
+    static constexpr int stage_end(int s) { return s < S0_G ? S0_G : (s < S0_D ? S0_D : (s < S0_Q ? S0_Q : S_END)); }
+    static constexpr int slot_size(int s) { return s < S0_G ? SZ_W : (s < S0_D ? SZ_G : (s < S0_Q ? SZ_D : SZ_Q)); }
 };
+template <class CFG>
+struct SlotTab {
+    int pos[CFG::S_END];
+    int need[CFG::S_END];
+};
+template <class CFG>
+constexpr SlotTab<CFG> make_slot_tab() {
+    SlotTab<CFG> t{};
+    int pos = 0;
+    for (int s = 0; s < CFG::S_END; s++) {
+        const int sz = CFG::slot_size(s);
+        if (pos + sz > CFG::RING) pos = 0;
+        t.pos[s] = pos;
+        t.need[s] = -1;
+        for (int j = s - 1; j >= 0; j--) {
+            if (t.pos[j] < pos + sz && pos < t.pos[j] + CFG::slot_size(j)) { t.need[s] = j; break; }
+        }
+        pos += sz;
+    }
+    return t;
+}
+template <class CFG>
+struct Tabs { static constexpr SlotTab<CFG> T = make_slot_tab<CFG>(); };
+static_assert(Cfg4B::LDS_BYTES <= ENG_LDS_TOTAL, "LDS");
 
 // The loader's own LDS traffic goes through inline asm: hipcc treats an LDS-DMA in flight as a
 // pending LDS write that any ds_read / ds_write of the wave may alias and would put
@@ -113,20 +161,28 @@ __device__ __forceinline__ void eng_give_up(const Engine& a, lds_u32* abortp) {
 // ======================================================================================
 // LOADER
 // ======================================================================================
-// One slot = rows [row0, row0 + rows) of a [d][n] matrix: rows*n bytes of codes to the slot's
-// start, rows*(n/64) scales to ENG_SCALES_OFF.  Always 16 DMA instructions (vmcnt counts
-// instructions): the descriptors end with the slot's data, so pieces past it move nothing.
-__device__ __forceinline__ void load_slot(const int8_t* W, const float* S, int n, int row0, int rows,
-                                          lds_char* dst, int lane) {
+// One slot = rows [row0, row0 + rows) of a [d][n] matrix: `pieces` 1-KiB DMA pieces of codes to the
+// slot's start, the scales to soff.  Always 16 DMA instructions (vmcnt counts instructions, and
+// its immediate must be a constant): the surplus ones go to the dump area with an empty descriptor.
+__device__ __forceinline__ void load_slot(const int8_t* W, const float* S, int n, int row0, int rows, int pieces, int soff,
+                                          lds_char* dst, lds_char* dump, int lane) {
     const int cbytes = (row0 + rows) * n;                 // < 2^31 for every matrix of these models
     const int sbytes = (row0 + rows) * (n >> 6) * 4;
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(W), 0, cbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S), 0, sbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(W), 0, 0, 0x00020000);
     const int voff = row0 * n + lane * 16;
 #pragma unroll
-    for (int k = 0; k < 15; k++)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, voff, k * 1024, 0, 2 /* nt */);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + ENG_SCALES_OFF), 16,
+    for (int k = 0; k < 15; k++) {
+        if (k < pieces)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, voff, k * 1024, 0, 2 /* nt */);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (__attribute__((address_space(3))) void*)dump, 16, lane * 16, 0, 0, 2);
+        // (without this hipcc folds the identical surplus pieces into one, and the vmcnt arithmetic
+        // of the loader -- 16 instructions per slot -- publishes slots that have not landed)
+        asm volatile("" ::: "memory");
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + soff), 16,
                                              row0 * (n >> 6) * 4 + lane * 16, 0, 0, 2);
 }
 
@@ -134,35 +190,57 @@ template <class CFG>
 __device__ __forceinline__ void loader_main(const Engine& a, lds_char* ring, EngCtl* lc, int lane, int b) {
     lds_u32* abortp = (lds_u32*)&lc->abort;
     const int total = a.qkv_q ? CFG::S_END : CFG::S0_Q;
+    lds_char* dump = ring + CFG::OFF_DUMP;
+    const bool use_hold = (a.flags & 1) != 0;
     unsigned issued = 0, landed = 0;
     for (int s = 0; s < total; s++) {
-        if (s >= ENG_NS) {
-            // ring position s % NS is free once no consumer can still read slot s - NS
-            const unsigned need = (unsigned)(s - ENG_NS);
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
+        const int need = Tabs<CFG>::T.need[s];
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            // the slot's bytes are free once no consumer can still read slot `need`; while the consumers
+            // are polling global memory for a hand-off the loader keeps out of their way (flags & 1)
+            bool ok = true;
+            if (need >= 0 || use_hold) {
                 // min over the 15 consumers' words (lane 15 repeats lane 0's)
                 const unsigned p = row_min_u32(ldsa_load(&lc->prog[(lane & 15) < ENG_CW ? (lane & 15) : 0]));
-                const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)p);
-                if (m > need) break;
-                if (ldsa_load(&lc->abort)) return;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > ENG_TIMEOUT_TICKS) { if (lane == 0) eng_give_up(a, abortp); return; }
+                const int mp = __builtin_amdgcn_readfirstlane((int)p);
+                ok = mp > need;
+                // a poll for the activation of stage t holds back the slots of stages >= t (never those of
+                // the stage that produces it: the vector could not complete without them)
+                if (ok && use_hold) {
+                    const int t = CFG::stage_of(s);
+                    for (int u = 1; u <= t; u++) ok = ok && ldsa_load(&lc->hold[u]) == 0;
+                }
+                (void)mp;
+            }
+            if (ok) break;
+            // blocked: nothing more will be requested for a while, so publish what is in flight
+            if (issued - landed == 2) {
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                ldsa_store(&lc->landed, ++landed);
+            } else if (issued - landed == 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ldsa_store(&lc->landed, ++landed);
+            } else {
                 __builtin_amdgcn_s_sleep(1);
             }
+            if (ldsa_load(&lc->abort)) return;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > ENG_TIMEOUT_TICKS) { if (lane == 0) eng_give_up(a, abortp); return; }
         }
-        lds_char* dst = ring + (s % ENG_NS) * ENG_SLOT;
+        lds_char* dst = ring + Tabs<CFG>::T.pos[s];
+        ESTAMP(a, 32, s);
         if (s < CFG::S0_G) {
-            const int k = s - CFG::S0_W, r0 = CFG::RS_W * k;
-            load_slot(a.wo_q, a.wo_s, CFG::P, CFG::RW_W * b + r0, min(CFG::RS_W, CFG::RW_W - r0), dst, lane);
+            const int k = s - CFG::S0_W, r0 = CFG::RS_W * k, rows = min(CFG::RS_W, CFG::RW_W - r0);
+            load_slot(a.wo_q, a.wo_s, CFG::P, CFG::RW_W * b + r0, rows, eng_pieces(rows, CFG::P), CFG::SOFF_W, dst, dump, lane);
         } else if (s < CFG::S0_D) {
-            const int k = s - CFG::S0_G, r0 = CFG::RS_G * k;
-            load_slot(a.gu_q, a.gu_s, CFG::DIM, CFG::RW_G * b + r0, min(CFG::RS_G, CFG::RW_G - r0), dst, lane);
+            const int k = s - CFG::S0_G, r0 = CFG::RS_G * k, rows = min(CFG::RS_G, CFG::RW_G - r0);
+            load_slot(a.gu_q, a.gu_s, CFG::DIM, CFG::RW_G * b + r0, rows, eng_pieces(rows, CFG::DIM), CFG::SOFF_G, dst, dump, lane);
         } else if (s < CFG::S0_Q) {
-            const int k = s - CFG::S0_D, r0 = CFG::RS_D * k;
-            load_slot(a.dn_q, a.dn_s, CFG::HID, CFG::RW_D * b + r0, min(CFG::RS_D, CFG::RW_D - r0), dst, lane);
+            const int k = s - CFG::S0_D, r0 = CFG::RS_D * k, rows = min(CFG::RS_D, CFG::RW_D - r0);
+            load_slot(a.dn_q, a.dn_s, CFG::HID, CFG::RW_D * b + r0, rows, eng_pieces(rows, CFG::HID), CFG::SOFF_D, dst, dump, lane);
         } else {
-            const int k = s - CFG::S0_Q, r0 = CFG::RS_Q * k;
-            load_slot(a.qkv_q, a.qkv_s, CFG::DIM, CFG::RW_Q * b + r0, min(CFG::RS_Q, CFG::RW_Q - r0), dst, lane);
+            const int k = s - CFG::S0_Q, r0 = CFG::RS_Q * k, rows = min(CFG::RS_Q, CFG::RW_Q - r0);
+            load_slot(a.qkv_q, a.qkv_s, CFG::DIM, CFG::RW_Q * b + r0, rows, eng_pieces(rows, CFG::DIM), CFG::SOFF_Q, dst, dump, lane);
         }
         issued++;
         if (issued - landed > ENG_INFLIGHT) {
@@ -172,10 +250,11 @@ __device__ __forceinline__ void loader_main(const Engine& a, lds_char* ring, Eng
             ldsa_store(&lc->landed, landed);
         }
     }
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    ldsa_store(&lc->landed, issued - 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ldsa_store(&lc->landed, issued);
+    while (landed < issued) {
+        if (issued - landed == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ldsa_store(&lc->landed, ++landed);
+    }
 }
 
 // ======================================================================================
@@ -222,21 +301,44 @@ __device__ __forceinline__ void cons_progress(ConsCtx& c, int next_slot) {
     if (c.lane == 0) __hip_atomic_store((lds_u32*)&c.lc->prog[c.cw], (unsigned)next_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// one 256-value block of a handed-off fp32 vector: poll until no lane sees the sentinel
-__device__ __forceinline__ float4 poll_block(ConsCtx& c, __amdgpu_buffer_rsrc_t r, int blk) {
-    const int off = (blk * 256 + 4 * c.lane) * 4;         // past the vector: outside the descriptor, reads zero
+// While a wave polls global memory it holds the loader off (flags & 1): the poll's round trip is
+// then one trip through an idle memory pipeline instead of a wait behind 32-48 KB of weight pieces.
+__device__ __forceinline__ void hold_on(ConsCtx& c, int t) {
+    if (c.lane == 0) __hip_atomic_fetch_add((lds_u32*)&c.lc->hold[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void hold_off(ConsCtx& c, int t) {
+    if (c.lane == 0) __hip_atomic_fetch_sub((lds_u32*)&c.lc->hold[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool no_sentinel(v4i v) {
+    return (unsigned)v.x != Q3_ENG_SENTINEL && (unsigned)v.y != Q3_ENG_SENTINEL && (unsigned)v.z != Q3_ENG_SENTINEL &&
+           (unsigned)v.w != Q3_ENG_SENTINEL;
+}
+// K 256-value blocks (blk0, blk0 + 15, ...) of a handed-off fp32 vector: poll, all K loads in flight together,
+// until no lane sees the sentinel in any of them
+template <int K>
+__device__ __forceinline__ void poll_blocks(ConsCtx& c, __amdgpu_buffer_rsrc_t r, int blk0, int nblk, int stage, float4 (&out)[K]) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    v4i v;
+    v4i v[K];
+    hold_on(c, stage);
     for (;;) {
-        v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */);
-        const bool ok = (unsigned)v.x != Q3_ENG_SENTINEL && (unsigned)v.y != Q3_ENG_SENTINEL &&
-                        (unsigned)v.z != Q3_ENG_SENTINEL && (unsigned)v.w != Q3_ENG_SENTINEL;
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int blk = blk0 + ENG_CW * k;
+            // (a block past the vector: offset outside the descriptor, reads zero)
+            const int off = blk < nblk ? (blk * 256 + 4 * c.lane) * 4 : 0x7ffffff0;
+            v[k] = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) ok = ok && no_sentinel(v[k]);
         if (__all(ok)) break;
         if (eng_dead(c.abortp)) { c.dead = true; break; }
         if (__builtin_amdgcn_s_memrealtime() - t0 > ENG_TIMEOUT_TICKS) { if (c.lane == 0) eng_give_up(*c.a, c.abortp); c.dead = true; break; }
         __builtin_amdgcn_s_sleep(1);
     }
-    return __builtin_bit_cast(float4, v);
+    hold_off(c, stage);
+#pragma unroll
+    for (int k = 0; k < K; k++) out[k] = __builtin_bit_cast(float4, v[k]);
 }
 // publish one value of a handed-off vector (write-through; a value that happens to carry the
 // sentinel's bits -- a NaN with that payload -- goes out as the canonical NaN instead)
@@ -248,10 +350,10 @@ __device__ __forceinline__ void publish(float* p, float v) {
 
 // row r of a landed slot . quantised activation held in registers; tile_dot's arithmetic
 template <int NJ>
-__device__ __forceinline__ float row_dot(const lds_char* slot, int r, int n, const v4i (&xv)[NJ], const float (&sx)[NJ], int lane) {
+__device__ __forceinline__ float row_dot(const lds_char* slot, int soff, int r, int n, const v4i (&xv)[NJ], const float (&sx)[NJ], int lane) {
     const lds_char* codes = slot + r * n;
     const __attribute__((address_space(3))) float* sc =
-        (const __attribute__((address_space(3))) float*)(slot + ENG_SCALES_OFF) + r * (n >> 6);
+        (const __attribute__((address_space(3))) float*)(slot + soff) + r * (n >> 6);
     const int quad = lane >> 2;
     float acc = 0.0f;
 #pragma unroll
@@ -285,7 +387,7 @@ __device__ __forceinline__ void load_act(const int8_t* lq, const float* ls, int 
 
 // gather a handed-off fp32 vector of n values into LDS (waves take blocks cw, cw+15, ..), then
 // rmsnorm with weight nw + q8_quantize (prepare_activation's arithmetic): codes/scales in LDS
-__device__ __forceinline__ void stage_in_norm(ConsCtx& c, const float* vec, const float* nw, int n, float* xl,
+__device__ __forceinline__ void stage_in_norm(ConsCtx& c, const float* vec, const float* nw, int n, int stage, float* xl,
                                               int8_t* lq, float* ls) {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vec), 0, n * 4, 0x00020000);
     const int nb = (n + 255) >> 8;
@@ -294,7 +396,9 @@ __device__ __forceinline__ void stage_in_norm(ConsCtx& c, const float* vec, cons
     if (myblk < nb && myblk * 256 + 4 * c.lane < n) gw = *reinterpret_cast<const float4*>(nw + myblk * 256 + 4 * c.lane);
     float4 own = make_float4(0.f, 0.f, 0.f, 0.f);
     if (myblk < nb) {
-        own = poll_block(c, r, myblk);
+        float4 got[1];
+        poll_blocks<1>(c, r, myblk, nb, stage, got);
+        own = got[0];
         if (myblk * 256 + 4 * c.lane < n) *reinterpret_cast<float4*>(xl + myblk * 256 + 4 * c.lane) = own;
     }
     cons_sync(c);
@@ -330,9 +434,11 @@ template <class CFG>
 __device__ __forceinline__ void consumer_main(const Engine& a, char* smem, lds_char* ring, EngCtl* lc, int cw, int lane, int b) {
     ConsCtx c;
     c.a = &a; c.lc = lc; c.abortp = (lds_u32*)&lc->abort; c.sync_target = 0; c.cw = cw; c.lane = lane; c.dead = false;
-    float* xl = reinterpret_cast<float*>(smem + ENG_NS * ENG_SLOT);
-    int8_t* lq = reinterpret_cast<int8_t*>(xl + CFG::DIM);
-    float* ls = reinterpret_cast<float*>(lq + CFG::HID);
+    float* xl = reinterpret_cast<float*>(smem + CFG::OFF_R1);        // fp32 x of the norm stages ...
+    int8_t* lq1 = reinterpret_cast<int8_t*>(smem + CFG::OFF_R1);     // ... or the codes of the Wo / down stages
+    int8_t* lq2 = reinterpret_cast<int8_t*>(smem + CFG::OFF_R2);     // codes of the norm stages
+    float* ls = reinterpret_cast<float*>(smem + CFG::OFF_R3);
+    constexpr auto& TAB = Tabs<CFG>::T;
     const bool has_q = a.qkv_q != nullptr;
 
     // which set of hand-off vectors this launch uses (the other one is poisoned for the next launch)
@@ -352,28 +458,31 @@ __device__ __forceinline__ void consumer_main(const Engine& a, char* smem, lds_c
         (void)sent;
     }
 
+    CSTAMP(0);
     // ================= Wo + residual (activation: attention output codes, plain memory) =================
     float xres = 0.0f;                                    // this wave's residual row (waves 0..9), carried Wo -> down
     if (cw < CFG::RW_W) xres = a.x[CFG::RW_W * b + cw];
     {
         if (cw < CFG::P / 1024) {
             const v4i v = reinterpret_cast<const v4i*>(a.att_q)[cw * 64 + lane];
-            reinterpret_cast<v4i*>(lq)[cw * 64 + lane] = v;
+            reinterpret_cast<v4i*>(lq1)[cw * 64 + lane] = v;
         } else if (cw == CFG::P / 1024 && lane < CFG::P / 64) {
             ls[lane] = a.att_s[lane];
         }
         cons_sync(c);
         v4i xv[CFG::NJ_P];
         float sx[CFG::NJ_P];
-        load_act<CFG::NJ_P>(lq, ls, CFG::P, lane, xv, sx);
+        load_act<CFG::NJ_P>(lq1, ls, CFG::P, lane, xv, sx);
         cons_sync(c);                                     // every wave has its copy: lq/ls may be rewritten
+        CSTAMP(1);
         if (cw < CFG::RW_W) {
             const int s = CFG::S0_W + cw / CFG::RS_W;
             cons_wait_slot(c, s);
-            const float acc = row_dot<CFG::NJ_P>(ring + (s % ENG_NS) * ENG_SLOT, cw % CFG::RS_W, CFG::P, xv, sx, lane);
+            const float acc = row_dot<CFG::NJ_P>(ring + TAB.pos[s], CFG::SOFF_W, cw % CFG::RS_W, CFG::P, xv, sx, lane);
             xres = xres + acc;                            // forward.c:295-298
             if (lane == 0) publish(xw + CFG::RW_W * b + cw, xres);
         }
+        CSTAMP(2);
         // next: the first gate/up slot holding one of this wave's row pairs (pair p = rows 2p, 2p+1)
         cons_progress(c, CFG::S0_G + (2 * cw) / CFG::RS_G);
     }
@@ -381,19 +490,21 @@ __device__ __forceinline__ void consumer_main(const Engine& a, char* smem, lds_c
 
     // ================= gate/up + SwiGLU (activation: rmsnorm(x)) =================
     {
-        stage_in_norm(c, xw, a.ffn_nw, CFG::DIM, xl, lq, ls);
+        stage_in_norm(c, xw, a.ffn_nw, CFG::DIM, 1, xl, lq2, ls);
+        CSTAMP(3);
         v4i xv[CFG::NJ_X];
         float sx[CFG::NJ_X];
-        load_act<CFG::NJ_X>(lq, ls, CFG::DIM, lane, xv, sx);
+        load_act<CFG::NJ_X>(lq2, ls, CFG::DIM, lane, xv, sx);
         cons_sync(c);
+        CSTAMP(4);
         constexpr int NPAIR = CFG::RW_G / 2;
 #pragma unroll 1
         for (int p = cw; p < NPAIR; p += ENG_CW) {
             const int s = CFG::S0_G + (2 * p) / CFG::RS_G, r = (2 * p) % CFG::RS_G;
             cons_wait_slot(c, s);
-            const lds_char* slot = ring + (s % ENG_NS) * ENG_SLOT;
-            const float g = row_dot<CFG::NJ_X>(slot, r, CFG::DIM, xv, sx, lane);
-            const float u = row_dot<CFG::NJ_X>(slot, r + 1, CFG::DIM, xv, sx, lane);
+            const lds_char* slot = ring + TAB.pos[s];
+            const float g = row_dot<CFG::NJ_X>(slot, CFG::SOFF_G, r, CFG::DIM, xv, sx, lane);
+            const float u = row_dot<CFG::NJ_X>(slot, CFG::SOFF_G, r + 1, CFG::DIM, xv, sx, lane);
             const float h = swiglu_pair(g, u);
             if (lane == 0) publish(hv + NPAIR * b + p, h);
             const int pn = p + ENG_CW;
@@ -402,54 +513,66 @@ __device__ __forceinline__ void consumer_main(const Engine& a, char* smem, lds_c
         }
     }
     if (c.dead) return;
+    CSTAMP(5);
 
     // ================= down + residual (activation: q8_quantize(h)) =================
     {
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(hv, 0, CFG::HID * 4, 0x00020000);
         constexpr int NB = (CFG::HID + 255) / 256;
-#pragma unroll 1
-        for (int blk = cw; blk < NB; blk += ENG_CW) {
-            const float4 v = poll_block(c, rh, blk);
-            const int i = blk * 256 + 4 * lane;
-            float scale;
-            const int packed = quantize_group16(v, scale);
-            if (i < CFG::HID) {
-                reinterpret_cast<int*>(lq)[i >> 2] = packed;
-                if ((lane & 15) == 0) ls[i >> 6] = scale;
+        constexpr int KB = (NB + ENG_CW - 1) / ENG_CW;        // blocks a wave may have to quantise
+        float4 hb[KB];
+        poll_blocks<KB>(c, rh, cw, NB, 2, hb);
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+            const int blk = cw + ENG_CW * k;
+            if (blk < NB) {                                   // wave-uniform
+                const int i = blk * 256 + 4 * lane;
+                float scale;
+                const int packed = quantize_group16(hb[k], scale);
+                if (i < CFG::HID) {
+                    reinterpret_cast<int*>(lq1)[i >> 2] = packed;
+                    if ((lane & 15) == 0) ls[i >> 6] = scale;
+                }
             }
         }
+        CSTAMP(6);
         cons_sync(c);
+        CSTAMP(7);
         if (cw < CFG::RW_D) {
             v4i xv[CFG::NJ_H];
             float sx[CFG::NJ_H];
-            load_act<CFG::NJ_H>(lq, ls, CFG::HID, lane, xv, sx);
+            load_act<CFG::NJ_H>(lq1, ls, CFG::HID, lane, xv, sx);
             const int s = CFG::S0_D + cw;
             cons_wait_slot(c, s);
-            const float acc = row_dot<CFG::NJ_H>(ring + (s % ENG_NS) * ENG_SLOT, 0, CFG::HID, xv, sx, lane);
+            const float acc = row_dot<CFG::NJ_H>(ring + TAB.pos[s], CFG::SOFF_D, 0, CFG::HID, xv, sx, lane);
             xres = xres + acc;                            // forward.c:335-338
             if (lane == 0) {
                 a.x[CFG::RW_D * b + cw] = xres;           // the residual the next launch starts from
                 if (has_q) publish(xd + CFG::RW_D * b + cw, xres);
             }
         }
+        CSTAMP(8);
         cons_progress(c, has_q ? CFG::S0_Q + cw / CFG::RS_Q : 0x7fffffff);
         cons_sync(c);                                     // lq/ls are rewritten by the next stage
+        CSTAMP(9);
     }
     if (c.dead || !has_q) return;
 
     // ================= next layer's Wq|Wk|Wv (activation: rmsnorm(x)) =================
     {
-        stage_in_norm(c, xd, a.att_nw_next, CFG::DIM, xl, lq, ls);
+        stage_in_norm(c, xd, a.att_nw_next, CFG::DIM, 3, xl, lq2, ls);
+        CSTAMP(10);
         v4i xv[CFG::NJ_X];
         float sx[CFG::NJ_X];
-        load_act<CFG::NJ_X>(lq, ls, CFG::DIM, lane, xv, sx);
+        load_act<CFG::NJ_X>(lq2, ls, CFG::DIM, lane, xv, sx);
 #pragma unroll 1
         for (int u = cw; u < CFG::RW_Q; u += ENG_CW) {
             const int s = CFG::S0_Q + u / CFG::RS_Q;
             cons_wait_slot(c, s);
-            const float acc = row_dot<CFG::NJ_X>(ring + (s % ENG_NS) * ENG_SLOT, u % CFG::RS_Q, CFG::DIM, xv, sx, lane);
+            const float acc = row_dot<CFG::NJ_X>(ring + TAB.pos[s], CFG::SOFF_Q, u % CFG::RS_Q, CFG::DIM, xv, sx, lane);
             if (lane == 0) a.qkv[CFG::RW_Q * b + u] = acc;    // read by the attention launch that follows
         }
+        CSTAMP(11);
     }
 }
 
@@ -459,8 +582,8 @@ __global__ __launch_bounds__(ENG_WAVES * 64) void k_engine(Engine a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.clk && tid == 0) atomicMin(a.clk, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    EngCtl* lc = reinterpret_cast<EngCtl*>(smem + ENG_NS * ENG_SLOT + CFG::DIM * 4 + CFG::HID + ((CFG::HID / 64 + 3) & ~3) * 4);
-    if (tid < 32) reinterpret_cast<unsigned*>(lc)[tid] = 0;     // landed, csync, abort, prog[] = 0
+    EngCtl* lc = reinterpret_cast<EngCtl*>(smem + CFG::OFF_CTL);
+    if (tid < 32) reinterpret_cast<unsigned*>(lc)[tid] = 0;     // landed, csync, abort, hold, prog[] = 0
     __syncthreads();       // the only s_barrier: before the wave classes diverge
     lds_char* ring = (lds_char*)smem;
     if (wave == 0) loader_main<CFG>(a, ring, lc, lane, blockIdx.x);
@@ -479,8 +602,7 @@ __global__ __launch_bounds__(ENG_WAVES * 64) void k_engine(Engine a) {
 }
 
 size_t engine_lds_bytes() {
-    using CFG = Cfg4B;
-    return (size_t)ENG_NS * ENG_SLOT + CFG::DIM * 4 + CFG::HID + ((CFG::HID / 64 + 3) & ~3) * 4 + sizeof(EngCtl);
+    return (size_t)Cfg4B::LDS_BYTES;
 }
 
 bool engine_supported(int dim, int hid, int H, int KV, int hd, int n_cus) {

@@ -84,7 +84,9 @@ struct Engine {
     float *xw, *hv, *xd;        // hand-off vectors, two sets each: [2][dim], [2][hid], [2][dim]; sentinel-poisoned
     GridSync* sync;             // epoch (launch parity) and the sticky abort flag
     unsigned* error;            // pinned host word
+    unsigned flags;             // bit 0: the loader pauses while consumer waves poll global memory
     unsigned long long* clk;    // profiling only
+    unsigned long long* stamps; // diagnostic builds only (-DQ3_ENG_STAMPS): [64 * workgroup + slot]
 };
 bool engine_supported(int dim, int hid, int H, int KV, int hd, int n_cus);
 size_t engine_lds_bytes();

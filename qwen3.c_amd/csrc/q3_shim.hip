@@ -141,6 +141,7 @@ struct Dev {
     bool use_engine = false;
     q3k::GridSync* esync = nullptr;
     float *eng_xw = nullptr, *eng_hv = nullptr, *eng_xd = nullptr;
+    unsigned eng_flags = 1;
     int ptokens_cap = 0;
     bool tap = false;
     std::vector<float> tap_host;
@@ -317,6 +318,8 @@ void setup_fused(Dev* d) {
         q3k::engine_poison(d->eng_xd, 2 * (size_t)d->dim, d->st);
         d->use_engine = true;
         d->fused_mlp = false;      // the engine covers those stages
+        const char* ef = getenv("Q3_ENG_FLAGS");      // experiments: bit 0 = loader pauses during polls
+        if (ef && *ef) d->eng_flags = (unsigned)atoi(ef);
     }
 }
 
@@ -413,7 +416,7 @@ Dev* attach(Model* m) {
         for (int i = 0; i < 2; i++) d->outbox[i] = dalloc<float>(d, d->dim + 1);
     }
     d->pgexec.assign((size_t)d->n_streams * 3, nullptr);
-    if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 4096); HIPCHK(hipMemset(d->stamps, 0, 4096 * 8)); }
+    if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 16384); HIPCHK(hipMemset(d->stamps, 0, 16384 * 8)); }
     HIPCHK(hipHostMalloc((void**)&d->ctl_host, sizeof(q3k::Ctl), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&d->amax_host, sizeof(int), hipHostMallocDefault));
     if (m->state.logits) {
@@ -660,11 +663,13 @@ void enqueue_step(Dev* d, q3k::AttMode mode, int stream = 0) {
             }
             e.att_q = d->att_q; e.att_s = d->att_s; e.x = d->x; e.qkv = d->qkv;
             e.xw = d->eng_xw; e.hv = d->eng_hv; e.xd = d->eng_xd; e.sync = d->esync; e.error = d->gerr_host;
+            e.flags = d->eng_flags;
             double bytes = q3_gemv_bytes(d->dim, d->P) + q3_gemv_bytes(2 * d->hid, d->dim) + q3_gemv_bytes(d->dim, d->hid);
             if (more) bytes += q3_gemv_bytes(d->P + 2 * d->KVD, d->dim);
             {
                 Timed t(d, more ? "engine" : "engine_last", bytes);
                 e.clk = t.clk();
+                e.stamps = (d->stamps && l == (d->l0 + d->l1) / 2) ? d->stamps : nullptr;
                 q3k::engine_layer(e, d->st);
             }
             if (d->tap) {
@@ -792,8 +797,8 @@ int q3_debug_stamps(Model* m, unsigned long long* out, int n) {
     Dev* d = lookup(m);
     if (!d || !d->stamps) return 0;
     HIPCHK(hipStreamSynchronize(d->st));
-    HIPCHK(hipMemcpy(out, d->stamps, (size_t)(n < 4096 ? n : 4096) * 8, hipMemcpyDeviceToHost));
-    return n < 4096 ? n : 4096;
+    HIPCHK(hipMemcpy(out, d->stamps, (size_t)(n < 16384 ? n : 16384) * 8, hipMemcpyDeviceToHost));
+    return n < 16384 ? n : 16384;
 }
 
 // diagnostic: `iters` back-to-back launches of one GEMV class cycling over layers [l_lo, l_hi),
