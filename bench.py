@@ -216,10 +216,7 @@ def main():
                    "parallelism": "1 GPU" if ngpu == 1 else f"pp{ngpu}: layer pipeline, RCCL send/recv of the residual, "
                                                             f"{ngpu} concurrent streams"},
     }
-    fused = hip.q3_fused_stages(m)
-    out["config"]["launch"] = "hipGraph of per-stage kernels" + (
-        "; gate/up + down fused across an in-launch hand-off (k_mlp)" if fused & 1 else "") + (
-        "; weight-streaming engine: Wo + gate/up + down + next QKV per launch (LDS-DMA ring, sentinel hand-offs)" if fused & 2 else "")
+    out["config"]["launch"] = "hipGraph of per-stage kernels"
     bpt = hip.q3_bytes_per_token(C.byref(p), pos0 + W + K // 2)
     if args.dtype == "fp16":
         # binary16 weights: 2 bytes per element instead of 1 + 4/64; everything else as in the Q8_0 count
@@ -275,9 +272,8 @@ def main():
             dus = hip.q3_prof_device_us(m, name.encode())
             if dus > 0:
                 kern[name]["us_device_clock"] = round(dus, 3)
-        dom = kern.get("mlp") or kern.get("gateup")
-        dom_fused = "mlp" in kern
-        dom_bytes = hip.q3_gemv_bytes(2 * p.hidden_dim, p.dim) + (hip.q3_gemv_bytes(p.dim, p.hidden_dim) if dom_fused else 0.0)
+        dom = kern.get("gateup")
+        dom_bytes = hip.q3_gemv_bytes(2 * p.hidden_dim, p.dim)
         if dom:
             # duration of a launch = first workgroup in .. last workgroup out by s_memrealtime inside
             # the kernel when available (agrees with rocprofv3's dispatch durations); the HIP-event
@@ -287,12 +283,11 @@ def main():
             traffic = None
             try:   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v6_pmc_traffic.json")))["kernels"]["gateup"]
-                if args.model == "4B" and not dom_fused:
+                if args.model == "4B":
                     traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
             except Exception:
                 pass
-            out["roofline"] = {"bound": "hbm", "kernel": ("k_mlp<3,8,10> (gate/up + SwiGLU + down, one launch)" if dom_fused
-                                                          else "k_gemv3<PRO_NORM,EPI_SWIGLU,3,8> (gate/up GEMV)"),
+            out["roofline"] = {"bound": "hbm", "kernel": "k_gemv3<PRO_NORM,EPI_SWIGLU,3,8> (gate/up GEMV)",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "timing": "in-kernel device clock (s_memrealtime, first workgroup in .. last out) of the "

@@ -88,14 +88,6 @@ int q3_device_attach(Model* m);
 int q3_device_attach_fp16(Model* m);
 void q3_device_detach(Model* m);
 void q3_device_sync(Model* m);
-/* Which stages of a layer run fused across an in-launch hand-off between the workgroups (one
- * launch instead of two or three; 256-CU device, layer shapes the kernels are compiled for;
- * Q3_FUSED=0 in the environment at attach keeps one launch per stage):
- *   bit 0  rmsnorm + gate/up + SwiGLU + down + residual (k_mlp)
- *   bit 1  the weight-streaming engine: Wo, gate/up, down and the next layer's QKV in one launch per layer
- *          (q3_engine.hip; Q3_ENGINE=0 at attach turns it off) */
-int q3_fused_stages(Model* m);
-
 /* One decode step without the logits copy: logits stay on the device.
  * Pair with q3_logits_fetch() or q3_device_argmax(). */
 void q3_forward_device(Model* m, int token, int pos);

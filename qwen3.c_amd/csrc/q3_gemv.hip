@@ -478,238 +478,6 @@ __global__ __launch_bounds__(1024) void k_gemv3(Gemv a, int ntasks, int tw, int 
     }
 }
 
-// ---- in-launch hand-off between the workgroups of a fused launch ------------------------
-// Guideline 16, counter form, the row of MI355X_MICROARCH.md's table that this matches: the
-// payload is stored write-through (sc1) by ONE wave of each workgroup, that wave drains
-// (vmcnt(0)) and ONE lane adds to the workgroup's shard of an agent-scope counter; ONE wave of
-// every consuming workgroup polls the eight shards with sc1 loads, then joins a workgroup
-// barrier, and only then are the handed-off bytes loaded -- every one of them by an sc1 load to
-// registers.  One workgroup per CU (1024 threads), so all of them are resident; every spin is
-// bounded by the 100 MHz clock, and a give-up raises *error and lets the launch drain.
-typedef __attribute__((address_space(1))) unsigned long long gs_u64;
-typedef __attribute__((address_space(1))) unsigned gs_u32;
-#define Q3_SYNC_TIMEOUT_TICKS 200000000ull     // 2 s
-
-__device__ __forceinline__ void grid_arrive(GridSync* s) {      // ONE lane, after the storing wave's vmcnt(0)
-    __hip_atomic_fetch_add((gs_u64*)&s->shard[blockIdx.x & 7][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// ONE wave; `done` = hand-offs completed before this one (all launches).  Shard i has been
-// incremented (done + 1) * n_i times once every workgroup has arrived, n_i = workgroups with blockIdx & 7 == i.
-__device__ __forceinline__ bool grid_wait(GridSync* s, unsigned long long done, int lane, unsigned* error) {
-    const int G = gridDim.x;
-    const int i = lane & 7;
-    const unsigned long long target = (done + 1ull) * (unsigned long long)((G - i + 7) >> 3);
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-        const unsigned long long v = __hip_atomic_load((gs_u64*)&s->shard[i][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all(v >= target)) return true;
-        const unsigned long long dead = __hip_atomic_load((gs_u64*)&s->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (dead || __builtin_amdgcn_s_memrealtime() - t0 > Q3_SYNC_TIMEOUT_TICKS) {
-            if (lane == 0) {
-                __hip_atomic_store((gs_u64*)&s->aborted, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store((gs_u32*)error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-// workgroup barrier that leaves vector-memory operations in flight (LDS traffic is drained)
-__device__ __forceinline__ void wg_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// ---- FUSED MLP: gate/up + SwiGLU -> hand-off of h -> down + residual, one launch -----------
-// Phase 1 is k_gemv3<PRO_NORM, EPI_SWIGLU> with one workgroup per CU.  A streaming wave that has
-// requested the last wave-load of its gate/up tile goes on requesting ITS ROW OF THE DOWN MATRIX
-// (workgroup b owns rows [b*dim/G, (b+1)*dim/G), one per streaming wave), so HBM keeps streaming
-// while the SwiGLU outputs travel: wave 0 publishes the workgroup's slice of h, arrives, and
-// polls until every workgroup has; then all 16 waves fetch h (sc1 loads straight into the
-// registers quantize_group16 wants: wave w takes the 256-blocks w, w+16, w+32), the codes meet
-// in LDS, and the streaming waves finish with the dot products of rows whose weights landed
-// during the hand-off.  Same arithmetic, same order as the two separate launches.
-constexpr int HB = 3;             // 256-blocks of h a wave may have to quantise (hid <= 16*3*256)
-
-#ifdef Q3_MLP_STAMPS
-// diagnostic build: stamps[16 * workgroup + slot] <- s_memrealtime; slots 0,1,3,4,5 by wave 0, the others by the last wave
-#define MSTAMP(slot, first) do { if (a.stamps && ((first) ? tid == 0 : tid == (int)blockDim.x - 64)) \
-    a.stamps[16 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define MSTAMP(slot, first) do {} while (0)
-#endif
-
-template <int NJ, int R, int NJD>
-__global__ __launch_bounds__(1024) void k_mlp(Mlp a, int ntasks, int tw) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NL = R * NJ;
-    constexpr int PRE = NL < Q3_GEMV_PRE ? NL : Q3_GEMV_PRE;
-    constexpr int E4 = PRE < 4 ? PRE : 4;
-    const int n = a.dim, hid = a.hid, d = 2 * a.hid;
-    const int nmax = hid > n ? hid : n;
-    const int tid = threadIdx.x, wave = tid >> 6;
-    int lane = tid & 63;
-    if (a.clk && tid == 0) atomicMin(a.clk, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    MSTAMP(0, true);
-    int8_t* lq = reinterpret_cast<int8_t*>(smem);
-    float* ls = reinterpret_cast<float*>(lq + nmax);
-    float* hout = ls + ((nmax >> 6) + 3 & ~3);           // [tw * R/2] SwiGLU outputs of this workgroup
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    const int nn = (int)(blockDim.x >> 6) - tw;
-    const int G = gridDim.x, b = blockIdx.x;
-
-    Gemv g1;                                             // phase 1 seen as a GEMV (prologue helpers)
-    g1.W = a.Wg; g1.S = a.Sg; g1.n = n; g1.d = d; g1.xf = a.x; g1.nw = a.nw; g1.xq = nullptr; g1.xs = nullptr;
-    g1.out = nullptr; g1.clk = nullptr; g1.stamps = nullptr;
-
-    const int tfirst = (int)(((long long)b * ntasks) / G);
-    const int tcount = (int)(((long long)(b + 1) * ntasks) / G) - tfirst;
-    const int drow0 = (int)(((long long)b * n) / G);
-    const int dcount = (int)(((long long)(b + 1) * n) / G) - drow0;
-    const int sw = uwave - nn;                           // streaming wave index (negative: preparing wave)
-    const bool has_down = sw >= 0 && sw < dcount;
-    const int drow = has_down ? drow0 + sw : n;          // row n lies outside the descriptor: zeros, no traffic
-    Tile<1, NJD> TD;
-    float res = 0.0f;
-
-    if (uwave < nn) {
-        prepare_activation<PRO_NORM>(g1, uwave, nn, lane, lq, ls);
-        wg_barrier();
-        MSTAMP(1, true);
-    } else {
-        const int task = (sw < tcount) ? tfirst + sw : ntasks;
-        const int row0 = task * R;
-        if (has_down) res = a.x[drow];
-        const WView wd = make_wview(a.Wg, a.Sg, d, n);
-        const WView wdn = make_wview(a.Wd, a.Sd, n, hid);
-        Tile<R, NJ> T;
-        const TileLane tl = tile_lane<NJ>(wd, lane);
-        const TileLane tln = tile_lane<NJD>(wdn, lane);
-        release_stream_waves();
-#pragma unroll
-        for (int q = 0; q < E4; q++) tile_issue_one<R, NJ>(T, wd, tl, row0, q / NJ, q % NJ);
-        wg_barrier();
-#pragma unroll
-        for (int q = E4; q < PRE; q++) tile_issue_one<R, NJ>(T, wd, tl, row0, q / NJ, q % NJ);
-        __builtin_amdgcn_sched_barrier(0);
-
-        asm volatile("" : "+v"(lane));
-        const int quad = lane >> 2;
-        float acc[R];
-#pragma unroll
-        for (int q = 0; q < NL; q++) {
-            const int r = q / NJ, j = q % NJ;
-            // look-ahead: the gate/up tile first, then straight on into the down row
-            if (q + PRE < NL) tile_issue_one<R, NJ>(T, wd, tl, row0, (q + PRE) / NJ, (q + PRE) % NJ);
-            else if (q + PRE - NL < NJD) tile_issue_one<1, NJD>(TD, wdn, tln, drow, 0, q + PRE - NL);
-            const int off = j * 1024 + lane * 16;
-            const bool act = off < n;
-            v4i xv = {0, 0, 0, 0};
-            float sx = 0.0f;
-            if (act) {
-                xv = *reinterpret_cast<const v4i*>(lq + off);
-                sx = ls[j * 16 + quad];
-            }
-            const int dsum = quad_sum(dot16(T.w[r][j], xv));
-            const float pp = ((float)dsum * T.s[r][j]) * sx;
-            if (j == 0) acc[r] = 0.0f;
-            acc[r] = act ? acc[r] + pp : acc[r];
-            if (j == NJ - 1) {
-                acc[r] = bfly_quads(acc[r]);
-                if (r & 1) {
-                    const float hv = swiglu_pair(acc[r - 1], acc[r]);
-                    if (lane == 0) hout[sw * (R / 2) + (r >> 1)] = hv;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int jd = (PRE < NJD ? PRE : NJD); jd < NJD; jd++) tile_issue_one<1, NJD>(TD, wdn, tln, drow, 0, jd);
-        __builtin_amdgcn_sched_barrier(0);
-        MSTAMP(2, false);
-    }
-    wg_barrier();                                        // hout complete
-    MSTAMP(3, true);
-
-    // ---- hand-off: publish this workgroup's slice of h, arrive, wait for everybody ----
-    unsigned long long done = 0;                         // wave 0: hand-offs completed before this launch
-    if (uwave == 0) {
-        // (read here, not at entry: the round trip would sit in front of this wave's share of the
-        // prologue; it completes under the drain below, i.e. before this workgroup arrives, and
-        // workgroup 0 rewrites the word only after every workgroup has arrived)
-        done = __hip_atomic_load((gs_u64*)&a.sync->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int nh = tcount * (R / 2);
-        const int i = tfirst * (R / 2) + lane;
-        if (lane < nh && i < hid)
-            __hip_atomic_store((__attribute__((address_space(1))) float*)(a.h + i), hout[lane], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        MSTAMP(4, true);
-        if (lane == 0) grid_arrive(a.sync);
-        grid_wait(a.sync, done, lane, a.error);
-        MSTAMP(5, true);
-    }
-    wg_barrier();
-    MSTAMP(6, false);
-
-    // ---- q8_quantize of h: every wave fetches (sc1) and quantises its own 256-blocks ----
-    {
-        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(a.h, 0, hid * 4, 0x00020000);
-        asm volatile("" : "+v"(lane));
-        float4 hv[HB];
-#pragma unroll
-        for (int k = 0; k < HB; k++) {
-            const int i = (uwave + 16 * k) * 256 + 4 * lane;   // past hid: outside the descriptor, reads zero
-            hv[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rh, i * 4, 0, 16 /* sc1 */));
-        }
-#pragma unroll
-        for (int k = 0; k < HB; k++) {
-            const int blk = uwave + 16 * k;
-            if (blk * 256 < hid) {                       // wave-uniform
-                const int i = blk * 256 + 4 * lane;
-                float scale;
-                const int packed = quantize_group16(hv[k], scale);
-                if (i < hid) {
-                    reinterpret_cast<int*>(lq)[i >> 2] = packed;
-                    if ((lane & 15) == 0) ls[i >> 6] = scale;
-                }
-            }
-        }
-    }
-    MSTAMP(7, false);
-    wg_barrier();
-    MSTAMP(8, false);
-
-    // ---- down + residual: the row this wave has been holding since the end of its gate/up tile ----
-    if (sw >= 0) {
-        float accd[1];
-        tile_dot<1, NJD>(TD, hid, lane, lq, ls, accd);
-        if (has_down && lane == 0) a.x[drow] = res + accd[0];
-    }
-    MSTAMP(9, false);
-    if (b == 0 && tid == 0) a.sync->epoch = done + 1ull;
-    if (a.clk) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == (int)blockDim.x - 64) atomicMax(a.clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    }
-}
-
-bool mlp_fused_supported(int dim, int hid, int n_cus) {
-    // compiled for the Qwen3-4B layer shape; one workgroup per CU, all 256 resident
-    return dim == 2560 && hid == 9728 && n_cus >= 256;
-}
-
-void mlp_fused(const Mlp& m, hipStream_t st) {
-    constexpr int NJ = 3, R = 8, NJD = 10, TW = 10, G = 256;
-    const int ntasks = (2 * m.hid + R - 1) / R;
-    const int nmax = m.hid > m.dim ? m.hid : m.dim;
-    const size_t lds = (size_t)nmax + (size_t)(((nmax >> 6) + 3) & ~3) * 4 + (size_t)TW * (R / 2) * 4 + 64;
-    hipLaunchKernelGGL((k_mlp<NJ, R, NJD>), dim3(G), dim3(1024), lds, st, m, ntasks, TW);
-}
-
 // ---- LOOP kernel (the classifier): waves walk over tasks, two tiles in flight ----------
 template <int PRO, int EPI, int NJ, int R, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_gemv2(Gemv a, int ntasks, int tw) {

@@ -37,62 +37,6 @@ struct Gemv {
 
 void gemv(const Gemv& g, Pro pro, Epi epi, hipStream_t st);
 
-// ---- stages fused across an in-launch hand-off (q3_gemv.hip: k_mlp) ---------------------
-// Arrival counters of the workgroups of a fused launch (cdna_hip_programming.md Guideline 16,
-// counter form).  One per device context, zeroed once at attach; the counters only ever count
-// up, `epoch` carries the number of completed hand-offs from launch to launch (kernel
-// arguments are frozen under graph replay, device memory is not).
-struct GridSync {
-    unsigned long long shard[8][16];     // shard = blockIdx & 7, one 128-B line each
-    unsigned long long epoch;
-    unsigned long long aborted;          // sticky: a spin gave up; later waits return at once
-    unsigned long long pad[14];
-};
-// rmsnorm + quantise + gate/up + SwiGLU (forward.c:303-321), hand-off of h between the
-// workgroups, quantise + down + residual (forward.c:326-338) in ONE launch: the down weights
-// stream in while the hand-off is in progress.
-struct Mlp {
-    const int8_t* Wg;  // gate/up rows interleaved [2*hid][dim]
-    const float* Sg;
-    const int8_t* Wd;  // down [dim][hid]
-    const float* Sd;
-    int dim, hid;
-    float* x;          // residual, in and out [dim]
-    const float* nw;   // ffn RMSNorm weight [dim]
-    float* h;          // scratch [hid]: the SwiGLU output, handed from workgroup to workgroup inside the launch
-    GridSync* sync;
-    unsigned* error;   // pinned host word, raised when a bounded spin gives up
-    unsigned long long* clk;   // profiling only: as in Gemv
-    unsigned long long* stamps;   // diagnostic builds only (-DQ3_MLP_STAMPS): [16 * workgroup + slot]
-};
-bool mlp_fused_supported(int dim, int hid, int n_cus);
-void mlp_fused(const Mlp& m, hipStream_t st);
-
-// ---- the weight-streaming engine (q3_engine.hip): Wo, gate/up, down and the next layer's
-// Wq|Wk|Wv as one launch, weights through an LDS ring fed by LDS-DMA, hand-offs between the
-// workgroups by sentinel-tagged write-through stores ------------------------------------
-#define Q3_ENG_SENTINEL 0x7fc0deadu      // "not yet written": a NaN no arithmetic of the step produces
-struct Engine {
-    const int8_t *wo_q, *gu_q, *dn_q, *qkv_q;     // this layer's Wo, gate/up (interleaved), down; next layer's Wq|Wk|Wv (null: none)
-    const float *wo_s, *gu_s, *dn_s, *qkv_s;
-    const float* ffn_nw;        // this layer's ffn RMSNorm weight
-    const float* att_nw_next;   // next layer's attention RMSNorm weight (with qkv_q)
-    const int8_t* att_q;        // attention output codes [P] and scales [P/64] (plain memory, previous launch)
-    const float* att_s;
-    float* x;                   // residual [dim]: in (entering Wo) and out (after down), plain memory
-    float* qkv;                 // out: next layer's raw projections [P + 2 KVD], plain memory
-    float *xw, *hv, *xd;        // hand-off vectors, two sets each: [2][dim], [2][hid], [2][dim]; sentinel-poisoned
-    GridSync* sync;             // epoch (launch parity) and the sticky abort flag
-    unsigned* error;            // pinned host word
-    unsigned flags;             // bit 0: the loader pauses while consumer waves poll global memory
-    unsigned long long* clk;    // profiling only
-    unsigned long long* stamps; // diagnostic builds only (-DQ3_ENG_STAMPS): [64 * workgroup + slot]
-};
-bool engine_supported(int dim, int hid, int H, int KV, int hd, int n_cus);
-size_t engine_lds_bytes();
-void engine_layer(const Engine& e, hipStream_t st);
-void engine_poison(float* p, size_t n, hipStream_t st);
-
 struct Attn {
     const Ctl* ctl;      // pos is read on the device
     const float* qkv;    // raw projections of this step: q[P] | k[KVD] | v[KVD]

@@ -133,15 +133,6 @@ struct Dev {
     unsigned long long* seed_dev = nullptr;
     int* samp_tok = nullptr;      // device slot + pinned host copy of the sampled token
     int* samp_tok_host = nullptr;
-    // stages fused across an in-launch hand-off (q3_gemv.hip: k_mlp)
-    q3k::GridSync* gsync = nullptr;
-    unsigned* gerr_host = nullptr;         // pinned: raised by a kernel whose bounded spin gave up
-    bool fused_mlp = false;
-    // weight-streaming engine (q3_engine.hip): Wo .. next layer's QKV as one launch per layer
-    bool use_engine = false;
-    q3k::GridSync* esync = nullptr;
-    float *eng_xw = nullptr, *eng_hv = nullptr, *eng_xd = nullptr;
-    unsigned eng_flags = 1;
     int ptokens_cap = 0;
     bool tap = false;
     std::vector<float> tap_host;
@@ -292,44 +283,6 @@ void pipeline_split(const ModelParams* p, int rank, int world, int* first, int* 
     q3_pipeline_layers(p, rank, world, first, count);
 }
 
-// Fused launches (stages joined by an in-launch hand-off between the workgroups): they need one
-// workgroup per CU resident at the same time, so they are used only on the full 256-CU device and
-// for the layer shapes they are compiled for; Q3_FUSED=0 keeps the one-launch-per-stage path.
-void setup_fused(Dev* d) {
-    const char* e = getenv("Q3_FUSED");
-    if (e && e[0] == '0') return;
-    if (d->fp16) return;
-    int ncu = 0;
-    HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d->device));
-    d->gsync = dalloc<q3k::GridSync>(d, 1);
-    HIPCHK(hipMemsetAsync(d->gsync, 0, sizeof(q3k::GridSync), d->st));
-    HIPCHK(hipHostMalloc((void**)&d->gerr_host, sizeof(unsigned), hipHostMallocDefault));
-    *d->gerr_host = 0;
-    d->fused_mlp = q3k::mlp_fused_supported(d->dim, d->hid, ncu);
-    const char* ee = getenv("Q3_ENGINE");
-    if (!(ee && ee[0] == '0') && q3k::engine_supported(d->dim, d->hid, d->H, d->KV, d->hd, ncu)) {
-        d->esync = dalloc<q3k::GridSync>(d, 1);
-        HIPCHK(hipMemsetAsync(d->esync, 0, sizeof(q3k::GridSync), d->st));
-        d->eng_xw = dalloc<float>(d, 2 * (size_t)d->dim);
-        d->eng_hv = dalloc<float>(d, 2 * (size_t)d->hid);
-        d->eng_xd = dalloc<float>(d, 2 * (size_t)d->dim);
-        q3k::engine_poison(d->eng_xw, 2 * (size_t)d->dim, d->st);
-        q3k::engine_poison(d->eng_hv, 2 * (size_t)d->hid, d->st);
-        q3k::engine_poison(d->eng_xd, 2 * (size_t)d->dim, d->st);
-        d->use_engine = true;
-        d->fused_mlp = false;      // the engine covers those stages
-        const char* ef = getenv("Q3_ENG_FLAGS");      // experiments: bit 0 = loader pauses during polls
-        if (ef && *ef) d->eng_flags = (unsigned)atoi(ef);
-    }
-}
-
-void check_fused_error(Dev* d) {
-    if (d->gerr_host && *d->gerr_host) {
-        Q3_DIE("a fused launch gave up waiting for its workgroups (in-launch hand-off timed out)");
-    }
-}
-
-
 Dev* attach(Model* m) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -425,7 +378,6 @@ Dev* attach(Model* m) {
         if (!d->logits_pinned) (void)hipGetLastError();
     }
     d->tap_host.assign((size_t)d->L * d->dim, 0.0f);
-    setup_fused(d);
     HIPCHK(hipStreamSynchronize(d->st));
 
     std::lock_guard<std::mutex> lk(g_mu);
@@ -577,16 +529,6 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
         g.stamps = stamp_for("wo");
         q3k::gemv(g, q3k::PRO_Q8, q3k::EPI_RESID, d->st);
     }
-    if (d->fused_mlp) {   // forward.c:303-338 in one launch (k_mlp)
-        q3k::Mlp mm;
-        memset(&mm, 0, sizeof(mm));
-        mm.Wg = L.gu_q; mm.Sg = L.gu_s; mm.Wd = L.dn_q; mm.Sd = L.dn_s; mm.dim = d->dim; mm.hid = d->hid;
-        mm.x = d->x; mm.nw = L.ffn_nw; mm.h = d->h; mm.sync = d->gsync; mm.error = d->gerr_host;
-        Timed t(d, "mlp", q3_gemv_bytes(2 * d->hid, d->dim) + q3_gemv_bytes(d->dim, d->hid));
-        mm.clk = t.clk();
-        mm.stamps = stamp_for("mlp");
-        q3k::mlp_fused(mm, d->st);
-    } else {
     {   // rmsnorm + quantise + gate/up + SwiGLU (forward.c:303-321)
         g.W = L.gu_q; g.S = L.gu_s; g.n = d->dim; g.d = 2 * d->hid;
         g.xf = d->x; g.nw = L.ffn_nw; g.out = d->h;
@@ -602,7 +544,6 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
         g.clk = t.clk();
         g.stamps = stamp_for("down");
         q3k::gemv(g, q3k::PRO_F32, q3k::EPI_RESID, d->st);
-    }
     }
     if (d->tap) {
         HIPCHK(hipMemcpyAsync(d->tap_dev + (size_t)l * d->dim, d->x, (size_t)d->dim * 4,
@@ -632,54 +573,7 @@ void enqueue_step(Dev* d, q3k::AttMode mode, int stream = 0) {
                         d->cs_cur, d->st);
         if (d->fp16 && d->has_embed) q3k::embed_half(d->ctl, d->emb_h, d->dim, d->x, d->st);
     }
-    if (d->use_engine && d->l1 > d->l0) {
-        // QKV of the first layer as its own launch; then per layer the attention launch and ONE engine
-        // launch: Wo, gate/up, down and the NEXT layer's QKV (q3_engine.hip)
-        {
-            const LayerDev& L = d->layers[d->l0];
-            q3k::Gemv g;
-            memset(&g, 0, sizeof(g));
-            g.W = L.qkv_q; g.S = L.qkv_s; g.n = d->dim; g.d = d->P + 2 * d->KVD;
-            g.xf = d->x; g.nw = L.att_nw; g.out = d->qkv;
-            Timed t(d, "qkv", q3_gemv_bytes(g.d, g.n));
-            g.clk = t.clk();
-            q3k::gemv(g, q3k::PRO_NORM, q3k::EPI_STORE, d->st);
-        }
-        for (int l = d->l0; l < d->l1; l++) {
-            const LayerDev& L = d->layers[l];
-            {
-                q3k::Attn a = attn_args(d, l, stream);
-                Timed t(d, "attn", 0.0);
-                q3k::attn(a, d->chunk_slots, mode, d->st);
-            }
-            const bool more = l + 1 < d->l1;
-            q3k::Engine e;
-            memset(&e, 0, sizeof(e));
-            e.wo_q = L.wo_q; e.wo_s = L.wo_s; e.gu_q = L.gu_q; e.gu_s = L.gu_s; e.dn_q = L.dn_q; e.dn_s = L.dn_s;
-            e.ffn_nw = L.ffn_nw;
-            if (more) {
-                const LayerDev& N = d->layers[l + 1];
-                e.qkv_q = N.qkv_q; e.qkv_s = N.qkv_s; e.att_nw_next = N.att_nw;
-            }
-            e.att_q = d->att_q; e.att_s = d->att_s; e.x = d->x; e.qkv = d->qkv;
-            e.xw = d->eng_xw; e.hv = d->eng_hv; e.xd = d->eng_xd; e.sync = d->esync; e.error = d->gerr_host;
-            e.flags = d->eng_flags;
-            double bytes = q3_gemv_bytes(d->dim, d->P) + q3_gemv_bytes(2 * d->hid, d->dim) + q3_gemv_bytes(d->dim, d->hid);
-            if (more) bytes += q3_gemv_bytes(d->P + 2 * d->KVD, d->dim);
-            {
-                Timed t(d, more ? "engine" : "engine_last", bytes);
-                e.clk = t.clk();
-                e.stamps = (d->stamps && l == (d->l0 + d->l1) / 2) ? d->stamps : nullptr;
-                q3k::engine_layer(e, d->st);
-            }
-            if (d->tap) {
-                HIPCHK(hipMemcpyAsync(d->tap_dev + (size_t)l * d->dim, d->x, (size_t)d->dim * 4,
-                                      hipMemcpyDeviceToDevice, d->st));
-            }
-        }
-    } else {
-        for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, mode, stream);
-    }
+    for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, mode, stream);
     if (d->has_cls) enqueue_head(d);
 }
 
@@ -720,7 +614,6 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
         HIPCHK(hipGraphLaunch(ex, d->st));
         if (to_host) {
             HIPCHK(hipStreamSynchronize(d->st));
-            check_fused_error(d);
         }
         return;
     }
@@ -895,22 +788,14 @@ void q3_device_detach(Model* m) {
     for (void* p : d->allocs) (void)hipFree(p);
     (void)hipHostFree(d->ctl_host);
     (void)hipHostFree(d->amax_host);
-    if (d->gerr_host) (void)hipHostFree(d->gerr_host);
     (void)hipStreamDestroy(d->st);
     delete d;
-}
-
-/* which stages of a layer run fused across an in-launch hand-off: bit 0 = gate/up + down (k_mlp) */
-int q3_fused_stages(Model* m) {
-    Dev* d = attach(m);
-    return (d->fused_mlp ? 1 : 0) | (d->use_engine ? 2 : 0);
 }
 
 void q3_device_sync(Model* m) {
     Dev* d = lookup(m);
     if (d) {
         HIPCHK(hipStreamSynchronize(d->st));
-        check_fused_error(d);
     }
 }
 

@@ -161,8 +161,6 @@ def hip_lib():
         lib.q3_device_attach.argtypes = [ModelP]
         lib.q3_device_detach.restype = None
         lib.q3_device_detach.argtypes = [ModelP]
-        lib.q3_fused_stages.restype = C.c_int
-        lib.q3_fused_stages.argtypes = [ModelP]
         lib.q3_device_sync.restype = None
         lib.q3_device_sync.argtypes = [ModelP]
         lib.q3_forward_device.restype = None
