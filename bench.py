@@ -88,7 +88,44 @@ def cpu_baseline(path, vocab, budget_s=20.0):
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": cores, "kind": kind,
             "sample": f"{n} greedy decode steps at pos 1..{pos - 1} of the same checkpoint, "
-                      f"OMP_NUM_THREADS={cores}" + (", upstream flags -Ofast" if kind == "reference" else "")}
+                      f"OMP_NUM_THREADS={cores}" + (", built -Ofast -march=x86-64-v3 -fopenmp (upstream CMakeLists.txt:17 "
+                                                     "uses -Ofast -march=native; the build host is not the GPU box)"
+                                                     if kind == "reference" else "")}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher: start N fresh rank processes (one per GPU) before
+    anything in THIS process has touched HIP, relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    probe = subprocess.run([sys.executable, "-c",
+                            f"import sys; sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); import q3lib; "
+                            "print(q3lib.hip_lib().q3_device_count())"],
+                           capture_output=True, text=True, timeout=600)
+    try:
+        ndev = int(probe.stdout.strip().splitlines()[-1])
+    except Exception:
+        raise SystemExit(f"[bench] cannot count HIP devices: {probe.stderr[-400:]}")
+    if ndev < n:
+        raise SystemExit(f"[bench] --gpus {n} but only {ndev} HIP device(s) visible: one process per GPU, no oversubscription")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), Q3_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    line, _ = procs[0].communicate()
+    bad = [r for r, pr in enumerate(procs) if pr.wait() != 0]
+    if bad:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        raise SystemExit(f"[bench] rank(s) {bad} failed")
+    sys.stdout.write(line)
+    sys.stdout.flush()
 
 
 def main():
@@ -103,16 +140,19 @@ def main():
                     help="fp16 = the contrast path of BASELINE config 5 (weights dequantised to binary16 at attach)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 512 / 4096 cached-position points")
     args = ap.parse_args()
 
     os.environ["OMP_NUM_THREADS"] = str(host_cores())   # before libgomp is first loaded
     # RCCL's bootstrap must stay on loopback: all ranks are on this node and the boxes'
     # other interfaces refuse connections
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)        # no launcher: be one (before any HIP call in this process)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        log(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    if args.gpus != world:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: refusing to measure a different job")
     ngpu = world
 
     import numpy as np
@@ -143,7 +183,10 @@ def main():
                     raise SystemExit("[bench] rank 0 never published the RCCL id")
                 time.sleep(0.05)
         raw = open(idfile, "rb").read()
+        if hip.q3_device_count() < ngpu:
+            raise SystemExit(f"[bench] {ngpu} ranks but {hip.q3_device_count()} HIP device(s): one process per GPU")
         assert hip.q3_pipeline_init(rank, ngpu, raw) == 0
+        assert hip.q3_pipeline_size() == ngpu, (hip.q3_pipeline_size(), ngpu)
         hip.q3_pipeline_allreduce_max(0.0)            # everybody has joined
         if rank == 0:
             os.remove(idfile)
@@ -217,6 +260,7 @@ def main():
                                                             f"{ngpu} concurrent streams"},
     }
     out["config"]["launch"] = "hipGraph of per-stage kernels"
+    out["rccl_comm_size"] = hip.q3_pipeline_size()
     bpt = hip.q3_bytes_per_token(C.byref(p), pos0 + W + K // 2)
     if args.dtype == "fp16":
         # binary16 weights: 2 bytes per element instead of 1 + 4/64; everything else as in the Q8_0 count
@@ -237,6 +281,26 @@ def main():
         hip.q3_pipeline_run(m, tok, pos + 8, K); hip.q3_device_sync(m)
         out["device_loop_tokens_per_s"] = round(K / (time.perf_counter() - t0), 2)
         pos += 8 + K
+    if ngpu == 1 and args.dtype == "q8" and not args.no_sweep:
+        # BASELINE config 3: the same decode step at 512 and 4096 cached positions (KV-tile + roofline
+        # sweep).  The cache is filled with finite pseudo-random rows (untimed), then real steps are timed.
+        ctx = {str(pos0): {"tokens_per_s": out["value"], "frac_of_hbm_roofline": out["hbm_roofline_frac_step"],
+                           "bytes_per_token": out["bytes_per_token"], "steps": K}}
+        Kc, Wc = min(K, 64), 8
+        for T in (512, 4096):
+            if T == pos0 or T + Kc + Wc + 8 > seq:
+                continue
+            hip.q3_kv_fill_random(m, T, 99)
+            t_tok, t_pos = run(Wc, tok, T)
+            hip.q3_device_sync(m)
+            t0 = time.perf_counter()
+            t_tok, t_pos = run(Kc, t_tok, t_pos)
+            hip.q3_device_sync(m)
+            rate = Kc / (time.perf_counter() - t0)
+            b_t = hip.q3_bytes_per_token(C.byref(p), T + Wc + Kc // 2)
+            ctx[str(T)] = {"tokens_per_s": round(rate, 2), "frac_of_hbm_roofline": round(rate * b_t / 1e9 / HBM_PEAK_GBS, 4),
+                           "bytes_per_token": int(b_t), "steps": Kc}
+        out["contexts"] = ctx
     if ngpu == 1 and pos + 600 < seq and args.dtype == "q8":
         # prompt ingestion (q3_prefill: 16 positions per pass, Q8_0 products on int8 MFMA; bit-identical
         # to feeding the prompt through forward()) -- reported next to the decode rate, not part of `value`

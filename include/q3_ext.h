@@ -195,6 +195,8 @@ double q3_prof_overhead_us(Model* m);   /* reserved, returns 0 */
 int q3_pipeline_unique_id(void* id_bytes);
 /* Join the communicator; must be called before q3_device_attach(). */
 int q3_pipeline_init(int rank, int world, const void* id_bytes);
+/* ranks of the RCCL communicator the pipeline runs on (1 = no pipeline) */
+int q3_pipeline_size(void);
 void q3_pipeline_layers(const ModelParams* p, int rank, int world, int* first, int* count);
 /* Which (stream, token index) rank `rank` handles at global tick `tick`; returns 0 when
  * the rank is idle on that tick (pipeline fill / drain). */

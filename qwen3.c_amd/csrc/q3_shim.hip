@@ -1557,9 +1557,25 @@ int q3_pipeline_unique_id(void* id_bytes) {
     return 0;
 }
 
+/* ranks of the RCCL communicator the pipeline runs on (1 = no pipeline) */
+int q3_pipeline_size(void) {
+    if (!g_pipe.on || !g_pipe.comm) return 1;
+    int n = 0;
+    if (ncclCommCount(g_pipe.comm, &n) != ncclSuccess) return -1;
+    return n;
+}
+
 int q3_pipeline_init(int rank, int world, const void* id_bytes) {
     die_if_no_gpu();
     if (world < 1 || rank < 0 || rank >= world) return -1;
+    {
+        // one process per GPU: two ranks on one device cannot form an RCCL communicator
+        int ndev = 0;
+        HIPCHK(hipGetDeviceCount(&ndev));
+        if (world > ndev && !getenv("Q3_DEVICE")) {
+            Q3_DIE("pipeline of %d ranks needs %d GPUs, %d visible (one process per GPU)", world, world, ndev);
+        }
+    }
     HIPCHK(hipSetDevice(pick_device()));
     g_pipe.rank = rank;
     g_pipe.world = world;

@@ -207,6 +207,7 @@ def hip_lib():
         lib.q3_pipeline_unique_id.argtypes = [C.c_void_p]
         lib.q3_pipeline_init.restype = C.c_int
         lib.q3_pipeline_init.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        lib.q3_pipeline_size.restype = C.c_int
         lib.q3_pipeline_layers.restype = None
         lib.q3_pipeline_layers.argtypes = [C.POINTER(ModelParams), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.q3_pipeline_schedule.restype = C.c_int
