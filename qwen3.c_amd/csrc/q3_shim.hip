@@ -75,12 +75,34 @@ struct Pipe {
     ncclComm_t comm = nullptr;
 };
 Pipe g_pipe;
-// stage identity for the next attach() (loopback self-test only); world 0 = use g_pipe
-struct NextStage { int rank = 0, world = 0; } g_next_stage;
-bool g_next_fp16 = false;       // the next attach() builds the fp16 contrast path (q3_device_attach_fp16)
+
+// What a registry entry was built from.  A Model freed by the reference's model_free() and a new one that
+// malloc happens to put at the same address must not inherit the old device state.
+struct ModelId {
+    const void* data = nullptr;
+    size_t size = 0;
+    const void *wq0 = nullptr, *qe = nullptr, *logits = nullptr;
+    int dim = 0, hid = 0, L = 0, V = 0, seq = 0;
+    bool operator==(const ModelId& o) const {
+        return data == o.data && size == o.size && wq0 == o.wq0 && qe == o.qe && logits == o.logits && dim == o.dim &&
+               hid == o.hid && L == o.L && V == o.V && seq == o.seq;
+    }
+};
+ModelId model_id(const Model* m) {
+    ModelId id;
+    id.data = m->data; id.size = (size_t)m->size;
+    id.wq0 = (m->weights.wq && m->params.n_layers > 0) ? (const void*)m->weights.wq[0].q : nullptr;
+    id.qe = m->weights.qe ? (const void*)m->weights.qe->q : nullptr;
+    id.logits = m->state.logits;
+    id.dim = m->params.dim; id.hid = m->params.hidden_dim; id.L = m->params.n_layers; id.V = m->params.vocab_size;
+    id.seq = m->params.seq_len;
+    return id;
+}
 
 struct Dev {
     Model* m = nullptr;
+    ModelId id;
+    float* logits_host = nullptr;  // m->state.logits at attach (registered with HIP when logits_pinned)
     int device = 0;
     hipStream_t st = nullptr;
     int dim = 0, hid = 0, L = 0, H = 0, KV = 0, hd = 0, P = 0, KVD = 0, V = 0, seq = 0;
@@ -283,11 +305,30 @@ void pipeline_split(const ModelParams* p, int rank, int world, int* first, int* 
     q3_pipeline_layers(p, rank, world, first, count);
 }
 
-Dev* attach(Model* m) {
+void destroy_dev(Dev* d);
+
+struct AttachOpts {
+    bool fp16 = false;
+    int stage_rank = 0, stage_world = 0;     // loopback self-test: this Dev is stage rank of world
+};
+
+Dev* attach(Model* m, const AttachOpts& opt = AttachOpts()) {
+    // creation is serialised (two threads calling forward() on a new Model must not both upload it); the
+    // registry lock itself is only held for look-ups
+    static std::mutex create_mu;
+    std::lock_guard<std::mutex> create_lk(create_mu);
     {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_reg.find(m);
-        if (it != g_reg.end()) return it->second;
+        Dev* stale = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            auto it = g_reg.find(m);
+            if (it != g_reg.end()) {
+                if (it->second->id == model_id(m)) return it->second;
+                stale = it->second;           // same address, different Model: the old one was freed behind our back
+                g_reg.erase(it);
+            }
+        }
+        if (stale) destroy_dev(stale);
     }
     die_if_no_gpu();
     const ModelParams* p = &m->params;
@@ -296,6 +337,8 @@ Dev* attach(Model* m) {
     if (p->dim % 64 || p->hidden_dim % 64) Q3_DIE("dim/hidden_dim must be multiples of 64");
     Dev* d = new Dev();
     d->m = m;
+    d->id = model_id(m);
+    d->logits_host = m->state.logits;
     d->device = pick_device();
     HIPCHK(hipSetDevice(d->device));
     HIPCHK(hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking));
@@ -304,8 +347,8 @@ Dev* attach(Model* m) {
     d->P = d->H * d->hd; d->KVD = d->KV * d->hd;
     d->seq_pad = (d->seq + Q3_ATT_CHUNK - 1) / Q3_ATT_CHUNK * Q3_ATT_CHUNK;
     d->l0 = 0; d->l1 = d->L;
-    if (g_next_stage.world > 0) {
-        d->rank = g_next_stage.rank; d->world = g_next_stage.world; d->loopback = true;
+    if (opt.stage_world > 0) {
+        d->rank = opt.stage_rank; d->world = opt.stage_world; d->loopback = true;
     } else if (g_pipe.on) {
         d->rank = g_pipe.rank; d->world = g_pipe.world;
     }
@@ -323,8 +366,7 @@ Dev* attach(Model* m) {
     upload_weights(d);
     {
         const char* ef = getenv("Q3_FP16");
-        d->fp16 = g_next_fp16 || (ef && ef[0] == '1');
-        g_next_fp16 = false;
+        d->fp16 = opt.fp16 || (ef && ef[0] == '1');
         if (d->fp16) {
             auto conv = [&](const int8_t* q, const float* sc, size_t elems) {
                 void* h = dalloc<uint16_t>(d, elems);
@@ -372,8 +414,8 @@ Dev* attach(Model* m) {
     if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 16384); HIPCHK(hipMemset(d->stamps, 0, 16384 * 8)); }
     HIPCHK(hipHostMalloc((void**)&d->ctl_host, sizeof(q3k::Ctl), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&d->amax_host, sizeof(int), hipHostMallocDefault));
-    if (m->state.logits) {
-        hipError_t e = hipHostRegister(m->state.logits, (size_t)d->V * sizeof(float), hipHostRegisterDefault);
+    if (d->logits_host) {
+        hipError_t e = hipHostRegister(d->logits_host, (size_t)d->V * sizeof(float), hipHostRegisterDefault);
         d->logits_pinned = (e == hipSuccess);
         if (!d->logits_pinned) (void)hipGetLastError();
     }
@@ -396,10 +438,40 @@ Dev* attach(Model* m) {
     return d;
 }
 
+// Tear a device context down.  Never dereferences the Model: by the time this runs (atexit, or a stale
+// registry entry) the reference's model_free() may have released it.
+void destroy_dev(Dev* d) {
+    (void)hipSetDevice(d->device);
+    (void)hipStreamSynchronize(d->st);
+    for (auto& ex : d->gexec) {
+        if (ex) (void)hipGraphExecDestroy(ex);
+    }
+    for (auto& ex : d->pgexec) {
+        if (ex) (void)hipGraphExecDestroy(ex);
+    }
+    for (auto& pr : d->ev_pool) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    if (d->logits_pinned) {
+        // (if the Model was freed first, the range is gone already and the runtime says so: ignored)
+        if (hipHostUnregister(d->logits_host) != hipSuccess) (void)hipGetLastError();
+    }
+    for (void* p : d->allocs) (void)hipFree(p);
+    (void)hipHostFree(d->ctl_host);
+    (void)hipHostFree(d->amax_host);
+    if (d->samp_tok_host) (void)hipHostFree(d->samp_tok_host);
+    (void)hipStreamDestroy(d->st);
+    delete d;
+}
+
+// the device context of THIS Model, or null (an entry left behind by a Model that was freed without
+// q3_device_detach() and whose address has been reused does not count)
 Dev* lookup(Model* m) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_reg.find(m);
-    return it == g_reg.end() ? nullptr : it->second;
+    if (it == g_reg.end() || !(it->second->id == model_id(m))) return nullptr;
+    return it->second;
 }
 
 // ---- profiling helpers ----------------------------------------------------
@@ -577,8 +649,10 @@ void enqueue_step(Dev* d, q3k::AttMode mode, int stream = 0) {
     if (d->has_cls) enqueue_head(d);
 }
 
+void launch_stage(Dev* d, q3k::AttMode mode, int stream);
+
 void fetch_logits_async(Dev* d) {
-    HIPCHK(hipMemcpyAsync(d->m->state.logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost, d->st));
+    HIPCHK(hipMemcpyAsync(d->logits_host, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost, d->st));
 }
 
 hipGraphExec_t build_graph(Dev* d, q3k::AttMode mode, bool with_logits) {
@@ -605,7 +679,21 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
     HIPCHK(hipSetDevice(d->device));
     if (d->world > 1) Q3_DIE("this Model is one stage of a %d-stage pipeline: use q3_pipeline_run()", d->world);
     const q3k::AttMode mode = q3k::attn_mode(pos);
-    d->ctl_host->token = token;
+    if (!to_host) {
+        // Asynchronous step (q3_forward_device): the caller may queue several of these without a sync, so
+        // {token, pos} must not travel through the one pinned host slot a later call would overwrite before
+        // this step's copy has run.  They go as immediate arguments of a one-thread kernel, and the step is
+        // the graph WITHOUT the ctl upload and without the 608-KB logits download.
+        prof_begin(d);
+        q3k::set_ctl(d->ctl, nullptr, token, pos, d->st);
+        launch_stage(d, mode, 0);
+        if (d->tap) {
+            HIPCHK(hipMemcpyAsync(d->tap_host.data(), d->tap_dev, d->tap_host.size() * 4, hipMemcpyDeviceToHost, d->st));
+        }
+        prof_collect(d);
+        return;
+    }
+    d->ctl_host->token = token;       // synchronous step: the slot is read before this call returns
     d->ctl_host->pos = pos;
     const bool pinned_ok = d->logits_pinned;
     if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
@@ -629,7 +717,7 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
             HIPCHK(hipStreamSynchronize(d->st));
         } else {
             HIPCHK(hipStreamSynchronize(d->st));
-            HIPCHK(hipMemcpy(d->m->state.logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(d->logits_host, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost));
         }
     }
     prof_collect(d);
@@ -758,8 +846,9 @@ int q3_device_attach(Model* m) {
 int q3_device_attach_fp16(Model* m) {
     if (!m) return -1;
     if (lookup(m)) Q3_DIE("q3_device_attach_fp16: this Model already has device state");
-    g_next_fp16 = true;
-    attach(m);
+    AttachOpts o;
+    o.fp16 = true;
+    attach(m, o);
     return 0;
 }
 
@@ -772,24 +861,7 @@ void q3_device_detach(Model* m) {
         d = it->second;
         g_reg.erase(it);
     }
-    (void)hipSetDevice(d->device);
-    (void)hipStreamSynchronize(d->st);
-    for (auto& ex : d->gexec) {
-        if (ex) (void)hipGraphExecDestroy(ex);
-    }
-    for (auto& ex : d->pgexec) {
-        if (ex) (void)hipGraphExecDestroy(ex);
-    }
-    for (auto& pr : d->ev_pool) {
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
-    }
-    if (d->logits_pinned) (void)hipHostUnregister(m->state.logits);
-    for (void* p : d->allocs) (void)hipFree(p);
-    (void)hipHostFree(d->ctl_host);
-    (void)hipHostFree(d->amax_host);
-    (void)hipStreamDestroy(d->st);
-    delete d;
+    destroy_dev(d);
 }
 
 void q3_device_sync(Model* m) {
@@ -840,6 +912,13 @@ namespace {
 
 void ensure_token_log(Dev* d, int per_stream) {
     if (per_stream <= d->ptokens_cap) return;
+    if (d->ptokens) {      // grow: the old log is released, not abandoned
+        HIPCHK(hipStreamSynchronize(d->st));
+        for (size_t i = 0; i < d->allocs.size(); i++) {
+            if (d->allocs[i] == (void*)d->ptokens) { d->allocs.erase(d->allocs.begin() + i); break; }
+        }
+        HIPCHK(hipFree(d->ptokens));
+    }
     d->ptokens = dalloc<int>(d, (size_t)per_stream * d->n_streams);
     d->ptokens_cap = per_stream;
 }
@@ -1240,9 +1319,7 @@ void q3_layer_step(Model* m, int layer, int pos, const float* x_in, float* x_out
     Dev* d = attach(m);
     if (layer < d->l0 || layer >= d->l1) Q3_DIE("layer %d is not on this device", layer);
     check_step_args(d, 0, pos);
-    d->ctl_host->token = 0;
-    d->ctl_host->pos = pos;
-    HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
+    q3k::set_ctl(d->ctl, nullptr, 0, pos, d->st);
     q3k::begin_step(d->ctl, nullptr, nullptr, d->dim, d->x, d->rope, d->hd, d->cs_cur, d->st);
     HIPCHK(hipMemcpyAsync(d->x, x_in, (size_t)d->dim * 4, hipMemcpyHostToDevice, d->st));
     enqueue_layer(d, layer, q3k::attn_mode(pos));
@@ -1340,21 +1417,25 @@ void swiglu(float* x1, float* x3, int size) {
     d1.to_host(x1, st);
 }
 
+void q3_op_attention(const float* q, const float* kcache, const float* vcache, int T, int n_heads,
+                     int n_kv_heads, int head_dim, float* out);
+
+/* reference attention() (src/forward.c:141-195): reads s->q (already normed and rotated by the caller) and
+ * rows 0..pos of the layer's HOST k/v cache, writes the head outputs to s->x_rms_norm; it neither norms,
+ * rotates nor appends to a cache.  The device's own cache and step buffers are not touched. */
 void attention(Model* m, int layer, int pos) {
-    Dev* d = attach(m);
-    if (layer < d->l0 || layer >= d->l1) Q3_DIE("layer %d is not on this device", layer);
-    check_step_args(d, 0, pos);
-    d->ctl_host->token = 0;
-    d->ctl_host->pos = pos;
-    HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
-    q3k::begin_step(d->ctl, nullptr, nullptr, d->dim, d->x, d->rope, d->hd, d->cs_cur, d->st);
-    q3k::Attn a = attn_args(d, layer);
-    a.of = d->att_f;
-    q3k::attn(a, d->chunk_slots, q3k::attn_mode(pos), d->st);
-    HIPCHK(hipStreamSynchronize(d->st));
-    if (m->state.x_rms_norm) {
-        HIPCHK(hipMemcpy(m->state.x_rms_norm, d->att_f, (size_t)d->P * 4, hipMemcpyDeviceToHost));
+    if (!m) Q3_DIE("attention: NULL model");
+    const ModelParams* p = &m->params;
+    const ForwardState* st = &m->state;
+    if (layer < 0 || layer >= p->n_layers || pos < 0 || pos >= p->seq_len) Q3_DIE("attention: layer %d / pos %d out of range", layer, pos);
+    if (!st->q || !st->k_cache || !st->v_cache || !st->x_rms_norm) {
+        Q3_DIE("attention(): this Model carries no host-side q / KV cache (opened with Q3_OPEN_DEFAULT); "
+               "the exported symbol has the reference's host-state semantics");
     }
+    const size_t kvd = (size_t)p->n_kv_heads * p->head_dim;
+    const size_t loff = (size_t)layer * p->seq_len * kvd;
+    q3_op_attention(st->q, st->k_cache + loff, st->v_cache + loff, pos + 1, p->n_heads, p->n_kv_heads, p->head_dim,
+                    st->x_rms_norm);
 }
 
 void q8_quantize(Q8Tensor* qt, float* x, int n, int block_size) {
@@ -1514,10 +1595,10 @@ int q3_pipeline_selftest(const char* path, int seq_len, int world, int first_tok
     for (int r = 0; r < world; r++) {
         ms[r] = q3_model_open(path, seq_len, 0);
         if (!ms[r]) return -1;
-        g_next_stage.rank = r;
-        g_next_stage.world = world;
-        ds[r] = attach(ms[r]);
-        g_next_stage.world = 0;
+        AttachOpts o;
+        o.stage_rank = r;
+        o.stage_world = world;
+        ds[r] = attach(ms[r], o);
     }
     for (int r = 0; r < world; r++) {
         ds[r]->loop_prev = ds[(r + world - 1) % world];

@@ -193,3 +193,85 @@ def test_family_layer_shapes_bit_exact(hip, host, orc, family):
     hip.q3_model_close(mp)
     hip.q3_model_close(mg)
     host.q3_model_close(mo)
+
+
+def test_back_to_back_async_steps_do_not_share_the_ctl_slot(hip, host):
+    """q3_forward_device() returns without a sync; several of them queued back to back must each run with
+    their own {token, pos} (round-1 ADVICE: the shared pinned slot was overwritten before the first copy ran)."""
+    mg, _mo = open_pair(hip, host, "small")
+    ma, _mb = open_pair(hip, host, "small")
+    feed = [int(t) for t in np.random.default_rng(12).integers(0, 1024, size=24)]
+    want = None
+    for pos, tok in enumerate(feed):
+        want = Q.logits_array(mg, hip.forward(mg, tok, pos))
+    for pos, tok in enumerate(feed):
+        hip.q3_forward_device(ma, tok, pos)           # no sync in between
+    hip.q3_logits_fetch(ma)
+    got = Q.logits_array(ma)
+    assert np.array_equal(got, want)
+    assert hip.q3_device_argmax(ma) == int(want.argmax())
+    for m in (mg, ma):
+        hip.q3_model_close(m)
+    host.q3_model_close(_mo); host.q3_model_close(_mb)
+
+
+def test_model_freed_by_the_reference_and_recreated(hip, host, orc):
+    """The real drop-in order of calls: model_create -> forward -> model_free (which knows nothing of the
+    device state) -> model_create -> forward.  The registry must neither touch the freed Model nor run the
+    new one on the old one's weights and KV cache."""
+    ref = Q.reference_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref not available")
+    orc.orc_set_mode(Q.ORC_TREE)
+    feed = [int(t) for t in np.random.default_rng(14).integers(0, 512, size=6)]
+    for round_, (name, vocab) in enumerate([("small", 1024), ("tiny", 512), ("small", 1024)]):
+        path = os.path.join(Q.tmp_dir(), f"{name}.bin")
+        Q.synth(name, path)
+        mr = ref.model_create(path.encode(), 0)
+        mo = host.q3_model_open(path.encode(), 0, 1)
+        for pos, tok in enumerate(feed):
+            a = Q.logits_array(mr, hip.forward(mr, tok % vocab, pos))
+            b = Q.logits_array(mo, orc.orc_forward(mo, tok % vocab, pos))
+            assert np.array_equal(a, b), (round_, pos)
+        ref.model_free(mr)                 # no q3_device_detach: the reference's own teardown order
+        host.q3_model_close(mo)
+
+
+def test_exported_attention_has_the_reference_semantics(hip, host, orc):
+    """attention(Model*, layer, pos) (reference src/forward.c:141-195): q and the host KV cache in, head
+    outputs to x_rms_norm, nothing else touched."""
+    path = os.path.join(Q.tmp_dir(), "small.bin")
+    Q.synth("small", path)
+    mg = host.q3_model_open(path.encode(), 0, 1)      # host state present; never attached to the device
+    mo = host.q3_model_open(path.encode(), 0, 1)
+    p = mg.contents.params
+    P, KVD, seq = p.n_heads * p.head_dim, p.n_kv_heads * p.head_dim, p.seq_len
+    rng = np.random.default_rng(21)
+    layer, pos = 1, 70
+    for m in (mg, mo):
+        st = m.contents.state
+        np.ctypeslib.as_array(st.q, shape=(P,))[:] = 0
+        np.ctypeslib.as_array(st.k_cache, shape=(p.n_layers, seq, KVD))[:] = 0
+        np.ctypeslib.as_array(st.v_cache, shape=(p.n_layers, seq, KVD))[:] = 0
+    q = rng.standard_normal(P).astype(np.float32)
+    k = rng.standard_normal((pos + 1, KVD)).astype(np.float32)
+    v = rng.standard_normal((pos + 1, KVD)).astype(np.float32)
+    for m in (mg, mo):
+        st = m.contents.state
+        np.ctypeslib.as_array(st.q, shape=(P,))[:] = q
+        np.ctypeslib.as_array(st.k_cache, shape=(p.n_layers, seq, KVD))[layer, :pos + 1] = k
+        np.ctypeslib.as_array(st.v_cache, shape=(p.n_layers, seq, KVD))[layer, :pos + 1] = v
+    hip.attention(mg, layer, pos)
+    orc.orc_set_mode(Q.ORC_TREE)
+    orc.orc_attention(mo, layer, pos)
+    got = np.ctypeslib.as_array(mg.contents.state.x_rms_norm, shape=(P,)).copy()
+    tree = np.ctypeslib.as_array(mo.contents.state.x_rms_norm, shape=(P,)).copy()
+    assert np.array_equal(got, tree)
+    orc.orc_set_mode(Q.ORC_REF)
+    orc.orc_attention(mo, layer, pos)
+    refo = np.ctypeslib.as_array(mo.contents.state.x_rms_norm, shape=(P,)).copy()
+    assert float(np.abs(got - refo).max() / np.abs(refo).max()) <= 2e-6
+    # the cache and q are inputs only
+    assert np.array_equal(np.ctypeslib.as_array(mg.contents.state.k_cache, shape=(p.n_layers, seq, KVD))[layer, :pos + 1], k)
+    assert np.array_equal(np.ctypeslib.as_array(mg.contents.state.q, shape=(P,)), q)
+    host.q3_model_close(mg); host.q3_model_close(mo)
