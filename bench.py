@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 512 / 4096 cached-position points")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the reference-loader + host-sampler loop")
     args = ap.parse_args()
 
     os.environ["OMP_NUM_THREADS"] = str(host_cores())   # before libgomp is first loaded
@@ -301,6 +302,26 @@ def main():
             ctx[str(T)] = {"tokens_per_s": round(rate, 2), "frac_of_hbm_roofline": round(rate * b_t / 1e9 / HBM_PEAK_GBS, 4),
                            "bytes_per_token": int(b_t), "steps": Kc}
         out["contexts"] = ctx
+    if ngpu == 1 and args.dtype == "q8" and not args.no_dropin:
+        # the drop-in as a reference user runs it: the reference's own loader and HOST sampler (whose
+        # softmax() call is this library's export) around forward(), oracle/_ref/libqwen3_dropin.so
+        drop = Q.dropin_lib()
+        if drop is not None:
+            md = drop.model_create(path.encode(), 512)
+            smp = drop.sampler_create(vocab, 1e-6, 0.9, 1234)      # the reference's "-t 0"
+            t_tok = START_TOKEN % vocab
+            for p_ in range(4):
+                t_tok = drop.sample(smp, drop.forward(md, t_tok, p_))
+            t0 = time.perf_counter()
+            nd = min(K, 64)
+            for p_ in range(4, 4 + nd):
+                t_tok = drop.sample(smp, drop.forward(md, t_tok, p_))
+            out["dropin_loop_tokens_per_s"] = round(nd / (time.perf_counter() - t0), 2)
+            out["dropin_loop"] = ("reference model_create + forward + host sample() (softmax export, qsort, xorshift) per token, "
+                                  "temperature 1e-6 / top-p 0.9, oracle/_ref/libqwen3_dropin.so")
+            drop.sampler_free(smp)
+            hip.q3_device_detach(md)
+            drop.model_free(md)
     if ngpu == 1 and pos + 600 < seq and args.dtype == "q8":
         # prompt ingestion (q3_prefill: 16 positions per pass, Q8_0 products on int8 MFMA; bit-identical
         # to feeding the prompt through forward()) -- reported next to the decode rate, not part of `value`

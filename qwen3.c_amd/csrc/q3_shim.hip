@@ -740,15 +740,57 @@ hipStream_t ops_stream() {
     return g_ops.st;
 }
 
+// Device buffers of the op hooks.  The reference's own code calls these hooks in its inner loops
+// (sample() -> softmax(logits, V) once per token, src/sampler.c:196), so a call must not pay for
+// hipMalloc / hipFree: released blocks go to a small cache and the next call of the same size gets
+// them back.  (The cache holds at most DBUF_CACHE_MAX blocks; larger one-off requests, e.g. the
+// dequantisation of a whole embedding table at load time, are really freed.)
+constexpr size_t DBUF_CACHE_MAX = 24;
+constexpr size_t DBUF_CACHE_BLOCK_LIMIT = 64u << 20;
+std::mutex g_dbuf_mu;
+std::vector<std::pair<size_t, void*>> g_dbuf_cache;      // (capacity, pointer)
+
+void* dbuf_take(size_t bytes, size_t* cap) {
+    {
+        std::lock_guard<std::mutex> lk(g_dbuf_mu);
+        size_t best = g_dbuf_cache.size();
+        for (size_t i = 0; i < g_dbuf_cache.size(); i++) {
+            if (g_dbuf_cache[i].first >= bytes && (best == g_dbuf_cache.size() || g_dbuf_cache[i].first < g_dbuf_cache[best].first)) best = i;
+        }
+        if (best < g_dbuf_cache.size() && g_dbuf_cache[best].first <= 2 * bytes + 4096) {
+            void* p = g_dbuf_cache[best].second;
+            *cap = g_dbuf_cache[best].first;
+            g_dbuf_cache.erase(g_dbuf_cache.begin() + best);
+            return p;
+        }
+    }
+    void* p = nullptr;
+    *cap = bytes ? bytes : 16;
+    HIPCHK(hipMalloc(&p, *cap));
+    return p;
+}
+void dbuf_give(void* p, size_t cap) {
+    if (cap <= DBUF_CACHE_BLOCK_LIMIT) {
+        std::lock_guard<std::mutex> lk(g_dbuf_mu);
+        if (g_dbuf_cache.size() < DBUF_CACHE_MAX) {
+            g_dbuf_cache.push_back({cap, p});
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 struct DBuf {   // RAII device buffer for the op hooks
     void* p = nullptr;
-    size_t bytes = 0;
-    explicit DBuf(size_t b) : bytes(b) { HIPCHK(hipMalloc(&p, b ? b : 16)); }
+    size_t bytes = 0, cap = 0;
+    explicit DBuf(size_t b) : bytes(b) { p = dbuf_take(b, &cap); }
     DBuf(const void* host, size_t b) : bytes(b) {
-        HIPCHK(hipMalloc(&p, b ? b : 16));
+        p = dbuf_take(b, &cap);
         if (b) HIPCHK(hipMemcpy(p, host, b, hipMemcpyHostToDevice));
     }
-    ~DBuf() { (void)hipFree(p); }
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    ~DBuf() { dbuf_give(p, cap); }
     void to_host(void* host, hipStream_t st) {
         HIPCHK(hipStreamSynchronize(st));
         if (bytes) HIPCHK(hipMemcpy(host, p, bytes, hipMemcpyDeviceToHost));

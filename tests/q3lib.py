@@ -329,6 +329,34 @@ def reference_lib(fast=False):
     return _cache[key]
 
 
+def dropin_lib(twin=False):
+    """The reference's library with src/forward.c and src/q8.c left out, linked against libq3hip.so
+    (oracle/Makefile): the drop-in as a reference user would run it.  `twin`: the same reference sources
+    linked against the CPU oracle's tree-order forward / softmax instead.  None when not built."""
+    key = "dropin_twin" if twin else "dropin"
+    if key not in _cache:
+        path = os.path.join(ORACLE_DIR, "_ref", "libqwen3_dropin_oracle.so" if twin else "libqwen3_dropin.so")
+        if not os.path.exists(path):
+            if os.path.exists("/root/reference/src/forward.c") and os.path.exists(os.path.join(PKG, "libq3hip.so")):
+                subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+            else:
+                _cache[key] = None
+                return None
+        lib = C.CDLL(path)
+        lib.model_create.restype = ModelP
+        lib.model_create.argtypes = [C.c_char_p, C.c_int]
+        lib.model_free.argtypes = [ModelP]
+        lib.forward.restype = c_float_p            # resolved through the library's own dependency (libq3hip.so / the shim)
+        lib.forward.argtypes = [ModelP, C.c_int, C.c_int]
+        lib.sampler_create.restype = C.POINTER(RefSampler)
+        lib.sampler_create.argtypes = [C.c_int, C.c_float, C.c_float, C.c_uint64]
+        lib.sampler_free.argtypes = [C.POINTER(RefSampler)]
+        lib.sample.restype = C.c_int
+        lib.sample.argtypes = [C.POINTER(RefSampler), c_float_p]
+        _cache[key] = lib
+    return _cache[key]
+
+
 def synth(name, path, seed=None, **overrides):
     """Write the named synthetic checkpoint to `path` (skipped if it already
     exists with the right size) and return the spec."""
