@@ -72,111 +72,134 @@ void rows_quantize(const float* x, int ldx, const float* w, int n, int rows, int
 // ---- Q8_0 GEMM on int8 MFMA ----------------------------------------------------------------
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
-// One workgroup = one tile of 16 rows x 16 tokens; its 4 waves split the groups by SUM16 column:
-// wave w owns the columns 4w..4w+3, i.e. groups 16b + 4w .. 16b + 4w + 3 of every block b of sixteen
-// groups -- four consecutive groups, so the group scales come as one float4 per row.  The sixteen
-// column sums then meet in LDS and wave 0 runs the butterfly: the same additions in the same order
-// as one wave doing it all, with four times the waves streaming the matrix.
-template <int EPI, int NT>            // NT = token tiles of 16 per workgroup: the weights are loaded once for all of them
-__global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 2 : 1)) void k_gemm_q8(const int8_t* __restrict__ W, const float* __restrict__ S, int n,
-                                                                  int d, const int8_t* __restrict__ xq,
-                                                                  const float* __restrict__ xs, int ntok,
-                                                                  float* __restrict__ out, int ldo) {
-    __shared__ float cols[NT][16][4][64];       // [token tile][column][output register][lane]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One wave = 16 rows x 16 tokens, all of K.  A workgroup = one row tile x up to four token tiles
+// (the waves read the same weight lines: one fetch from L2, the rest from the CU's L1).
+//
+// The decode GEMV (q3_gemv.hip) defines the result: per row, sixteen column sums col[c] = the
+// products p_g = ((float)dot_g * ws_g) * xs_g of the groups g = c, c+16, c+32, .. added in ascending
+// order, then the butterfly col[c] += col[c^8], ^4, ^2, ^1.  K = 64 is one Q8_0 group, so ONE
+// v_mfma_i32_16x16x64_i8 gives the exact int32 group dots of 16 rows x 16 tokens; a lane holds 4 of
+// them (4 rows of one token) and keeps the sixteen column sums of each in registers (64 VGPRs), walks
+// the groups in memory order -- every lane streams through its row 64 bytes at a time, four groups per
+// round with the next round's loads already in flight, every load a buffer load whose per-lane offset
+// is computed once -- and runs the butterfly once at the end: the GEMV's additions with the GEMV's
+// operands, so a prefilled prompt leaves bit-identical logits and KV cache (tests/test_gpu_prefill.py).
+//
+// Operand maps of v_mfma_i32_16x16x64_i8 (checked with asymmetric integer data by the op test):
+//   A: lane l holds A[row l&15][k = 16*(l>>4) .. +15];  B the same with token l&15
+//   D: lane l, register i holds D[row 4*(l>>4) + i][token l&15]
+//
+// Where it stands (profiles/r02_prefill_gemm_variants.json): 63 us for the gate/up GEMM of 64 tokens, for
+// 56 MB of weights (9 us of HBM time) and ~5 us of VALU issue for the fp32 scale-accumulate of 50 M group
+// dots -- neither roofline.  Variants measured this round, all bit-exact, none faster: the four waves
+// splitting the SUM16 columns instead of the tokens (round 1: 75 us); column pairs in butterfly order
+// folded into running trees, which needs 24 instead of 64 accumulator registers (80 us); three rounds of
+// weights in flight instead of one (67 us); two row tiles per workgroup (141 us) and 64 x 64 tiles with
+// sixteen waves (119 us).  The time follows the number of 64-byte row segments the CU's vector-memory
+// path has to gather per MFMA (16 rows x 64 B per operand load), not the bytes: the next step is to stage
+// whole 128-byte lines of both operands through LDS (the guide's "x through LDS in full lines" row) --
+// not built.
+struct GemmSub {          // four consecutive groups: this lane's k-slices and the scales it needs
+    v4i a[4], b[4];
+    float sw[4][4];       // [output row i][group]
+    float sx[4];
+};
+
+template <int EPI, bool AL4>          // AL4: n/64 is a multiple of 4 (scale quads are 16-byte aligned, no partial round)
+__global__ __launch_bounds__(256) void k_gemm_q8(const int8_t* __restrict__ W, const float* __restrict__ S, int n,
+                                                 int d, const int8_t* __restrict__ xq,
+                                                 const float* __restrict__ xs, int ntok,
+                                                 float* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int tt = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));        // token tile of this wave
     const int r0 = (int)blockIdx.x * 16;
     const int ng = n >> 6;
     const int li = lane & 15, kb = lane >> 4;
-    // A: row r0 + li (clamped: rows >= d are computed and dropped), 16 bytes at k-block kb of each group
-    const int arow = r0 + li < d ? r0 + li : d - 1;
-    const int8_t* ap = W + (size_t)arow * n + 16 * kb;
-    // B: token 16j + li of tile j (tokens >= ntok: clamped, dropped at the store)
-    const int8_t* bp[NT];
-    const float* xsp[NT];
+    const int arow = r0 + li < d ? r0 + li : d - 1;          // rows >= d: computed and dropped
+    const int tok = tt * 16 + li < ntok ? tt * 16 + li : ntok - 1;     // tokens >= ntok: clamped, dropped at the store
+    // buffer loads: per-lane offsets computed once, the group's offset is a scalar
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(W), 0, d * n, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S), 0, d * ng * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(xq), 0, ntok * n, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rXS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs), 0, ntok * ng * 4, 0x00020000);
+    const int va = arow * n + 16 * kb, vb = tok * n + 16 * kb, vxs = tok * ng * 4;
+    int vs[4];
 #pragma unroll
-    for (int j = 0; j < NT; j++) {
-        const int tok = 16 * j + li < ntok ? 16 * j + li : ntok - 1;
-        bp[j] = xq + (size_t)tok * n + 16 * kb;
-        xsp[j] = xs + (size_t)tok * ng;
-    }
-    const float* wsp[4];                         // scales of the 4 output rows of this lane
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int r = r0 + 4 * kb + i < d ? r0 + 4 * kb + i : d - 1;
-        wsp[i] = S + (size_t)r * ng;
-    }
-    float col[NT][4][4];                         // [token tile][column 4w + c][output register]
-#pragma unroll
-    for (int j = 0; j < NT; j++)
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) col[j][c][i] = 0.0f;
+    for (int i = 0; i < 4; i++) vs[i] = (r0 + 4 * kb + i < d ? r0 + 4 * kb + i : d - 1) * ng * 4;
 
-    for (int g0 = 4 * wave; g0 < ng; g0 += 16) {             // groups g0 .. g0+3
-        v4i a[4], b[NT][4];
-        float4 sw[4], sx[NT];
+    auto load_sub = [&](GemmSub& r, int g) {                 // groups g .. g+3 (g wave-uniform); past ng: clamped, never used
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const int g = g0 + c < ng ? g0 + c : ng - 1;
-            a[c] = *reinterpret_cast<const v4i*>(ap + (size_t)g * 64);
-#pragma unroll
-            for (int j = 0; j < NT; j++) b[j][c] = *reinterpret_cast<const v4i*>(bp[j] + (size_t)g * 64);
+            const int gc = AL4 ? g + c : (g + c < ng ? g + c : ng - 1);
+            r.a[c] = __builtin_amdgcn_raw_buffer_load_b128(rW, va, gc * 64, 0);
+            r.b[c] = __builtin_amdgcn_raw_buffer_load_b128(rX, vb, gc * 64, 0);
         }
-        if (g0 + 3 < ng && (ng & 3) == 0) {                   // 16-byte aligned scale quads
+        if (AL4) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) sw[i] = *reinterpret_cast<const float4*>(wsp[i] + g0);
-#pragma unroll
-            for (int j = 0; j < NT; j++) sx[j] = *reinterpret_cast<const float4*>(xsp[j] + g0);
+            for (int i = 0; i < 4; i++) {
+                const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rS, vs[i], g * 4, 0);
+                r.sw[i][0] = __int_as_float(q.x); r.sw[i][1] = __int_as_float(q.y);
+                r.sw[i][2] = __int_as_float(q.z); r.sw[i][3] = __int_as_float(q.w);
+            }
+            const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rXS, vxs, g * 4, 0);
+            r.sx[0] = __int_as_float(q.x); r.sx[1] = __int_as_float(q.y); r.sx[2] = __int_as_float(q.z); r.sx[3] = __int_as_float(q.w);
         } else {
-            const int g1 = g0 < ng ? g0 : ng - 1, g2 = g0 + 1 < ng ? g0 + 1 : ng - 1;
-            const int g3 = g0 + 2 < ng ? g0 + 2 : ng - 1, g4 = g0 + 3 < ng ? g0 + 3 : ng - 1;
 #pragma unroll
-            for (int i = 0; i < 4; i++) sw[i] = make_float4(wsp[i][g1], wsp[i][g2], wsp[i][g3], wsp[i][g4]);
+            for (int c = 0; c < 4; c++) {
+                const int gc = g + c < ng ? g + c : ng - 1;
 #pragma unroll
-            for (int j = 0; j < NT; j++) sx[j] = make_float4(xsp[j][g1], xsp[j][g2], xsp[j][g3], xsp[j][g4]);
+                for (int i = 0; i < 4; i++) r.sw[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vs[i], gc * 4, 0));
+                r.sx[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rXS, vxs, gc * 4, 0));
+            }
         }
+    };
+
+    float col[16][4];                                        // [SUM16 column][output register]
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if (g0 + c < ng) {                                // wave-uniform
+    for (int c = 0; c < 16; c++)
 #pragma unroll
-                for (int j = 0; j < NT; j++) {
+        for (int i = 0; i < 4; i++) col[c][i] = 0.0f;
+
+    GemmSub P, Q;                                            // ping / pong: one round computing, the next in flight
+    load_sub(P, 0);
+    for (int g0 = 0; g0 < ng; g0 += 16) {                    // 16 groups = one pass over the columns
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {                     // rounds of 4 groups, alternating register sets
+            const int g = g0 + 4 * q4;
+            if (g >= ng) break;                              // wave-uniform
+            GemmSub& cur = (q4 & 1) ? Q : P;
+            GemmSub& nxt = (q4 & 1) ? P : Q;
+            if (g + 4 < ng) load_sub(nxt, g + 4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (AL4 || g + c < ng) {
                     const v4i32 zero = {0, 0, 0, 0};
-                    const v4i32 dsum = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], b[j][c], zero, 0, 0, 0);
-                    const float sxc = c == 0 ? sx[j].x : (c == 1 ? sx[j].y : (c == 2 ? sx[j].z : sx[j].w));
+                    const v4i32 dd = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[c], cur.b[c], zero, 0, 0, 0);
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const float swc = c == 0 ? sw[i].x : (c == 1 ? sw[i].y : (c == 2 ? sw[i].z : sw[i].w));
-                        const float p = ((float)dsum[i] * swc) * sxc;
-                        col[j][c][i] = col[j][c][i] + p;
+                        const float p = ((float)dd[i] * cur.sw[i][c]) * cur.sx[c];
+                        col[4 * q4 + c][i] = col[4 * q4 + c][i] + p;
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-#pragma unroll
-    for (int j = 0; j < NT; j++)
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) cols[j][4 * wave + c][i][lane] = col[j][c][i];
-    __syncthreads();
-    if (wave >= NT) return;
-    // wave j finishes token tile j: butterfly col[c] += col[c^8], ^4, ^2, ^1
-    const int j = wave;
+    // butterfly col[c] += col[c^8], ^4, ^2, ^1
     float res[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         float t8[8], t4[4], t2[2];
 #pragma unroll
-        for (int c = 0; c < 8; c++) t8[c] = cols[j][c][i][lane] + cols[j][c + 8][i][lane];
+        for (int c = 0; c < 8; c++) t8[c] = col[c][i] + col[c + 8][i];
 #pragma unroll
         for (int c = 0; c < 4; c++) t4[c] = t8[c] + t8[c + 4];
 #pragma unroll
         for (int c = 0; c < 2; c++) t2[c] = t4[c] + t4[c + 2];
         res[i] = t2[0] + t2[1];
     }
-    const int tokj = 16 * j + li;
+    const int tokj = tt * 16 + li;
     if (tokj >= ntok) return;
     const int row = r0 + 4 * kb;
     if (EPI == EPI_SWIGLU) {
@@ -193,23 +216,22 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? 2 : 1)) void k_gemm_q
     }
 }
 
-template <int NT>
+template <bool AL4>
 static void launch_gemm(const int8_t* W, const float* S, int n, int d, const int8_t* xq, const float* xs, int ntok,
                         float* out, int ldo, Epi epi, hipStream_t st) {
-    const dim3 grid((d + 15) / 16), block(256);
-    if (epi == EPI_STORE) hipLaunchKernelGGL((k_gemm_q8<EPI_STORE, NT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
-    else if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_q8<EPI_RESID, NT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
-    else hipLaunchKernelGGL((k_gemm_q8<EPI_SWIGLU, NT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+    const dim3 grid((d + 15) / 16), block(64 * ((ntok + 15) / 16));
+    if (epi == EPI_STORE) hipLaunchKernelGGL((k_gemm_q8<EPI_STORE, AL4>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+    else if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_q8<EPI_RESID, AL4>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+    else hipLaunchKernelGGL((k_gemm_q8<EPI_SWIGLU, AL4>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
 }
 void gemm_q8(const int8_t* W, const float* S, int n, int d, const int8_t* xq, const float* xs, int ntok, float* out,
              int ldo, Epi epi, hipStream_t st) {
-    if (n % 64 || d % 2 || ntok < 1 || ntok > 64) {
+    if (n % 64 || d % 2 || ntok < 1 || ntok > 64 || (long long)d * n >= (1ll << 31)) {
         fprintf(stderr, "[q3hip] gemm_q8: bad shape (n=%d d=%d tokens=%d)\n", n, d, ntok);
         exit(EXIT_FAILURE);
     }
-    if (ntok <= 16) launch_gemm<1>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
-    else if (ntok <= 32) launch_gemm<2>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
-    else launch_gemm<4>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
+    if ((n >> 6) % 4 == 0) launch_gemm<true>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
+    else launch_gemm<false>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
 }
 
 // ---- per-token bookkeeping of a prefill chunk ----------------------------------------------
