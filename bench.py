@@ -367,7 +367,7 @@ def main():
             ach = round(dom_bytes / us_best / 1e3, 1)
             traffic = None
             try:   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_v6_pmc_traffic.json")))["kernels"]["gateup"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]["gateup"]
                 if args.model == "4B":
                     traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
             except Exception:
@@ -375,6 +375,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "k_gemv3<PRO_NORM,EPI_SWIGLU,3,8> (gate/up GEMV)",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "traffic_source": "profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+                                                 "of this workload (FETCH_SIZE doubled per the gfx950 note), committed -- not re-measured by this run",
                                "timing": "in-kernel device clock (s_memrealtime, first workgroup in .. last out) of the "
                                          "same launches that the HIP events bracket on the launch stream; "
                                          "us_per_launch_events includes the end-of-kernel release (~2 us)",

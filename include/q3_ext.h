@@ -84,7 +84,8 @@ int q3_device_attach(Model* m);
 /* The fp16 CONTRAST path (BASELINE config 5; nothing like it in the reference): attach with every Q8_0
  * matrix dequantised (q*s) and rounded to binary16 on the device; forward() then runs on those weights with
  * fp32 activations and no activation quantisation.  Must come before anything else touches the device for
- * this Model.  q3_prefill / the pipeline are Q8_0-only. */
+ * this Model.  q3_prefill works on such a Model too (its GEMMs then run on v_mfma_f32_16x16x32_f16 with the
+ * activation rows rounded to binary16); the pipeline is Q8_0-only. */
 int q3_device_attach_fp16(Model* m);
 void q3_device_detach(Model* m);
 void q3_device_sync(Model* m);

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
         a.os += (size_t)z * a.zs_os;
         a.part += (size_t)z * a.zs_part;
         a.tickets += (size_t)z * a.zs_tickets;
+        if (a.of) a.of += (size_t)z * a.zs_of;
     }
     constexpr int L4 = HD / 4;               // lanes holding one head as float4
     constexpr int CH = Q3_ATT_CHUNK;
@@ -506,6 +507,7 @@ __global__ __launch_bounds__(64) void k_attn_merge(Attn a_in) {
         a.oq += (size_t)z * a.zs_oq;
         a.os += (size_t)z * a.zs_os;
         a.part += (size_t)z * a.zs_part;
+        if (a.of) a.of += (size_t)z * a.zs_of;
     }
     constexpr int ST = HD + 2;
     constexpr int GPH = HD / 64;                // quantisation groups per head

@@ -19,6 +19,8 @@
 
 namespace q3k {
 
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
 __global__ void k_to_half(const int8_t* __restrict__ q, const float* __restrict__ s, size_t n, __half* __restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = __float2half_rn((float)q[i] * s[i >> 6]);
@@ -34,8 +36,6 @@ __global__ void k_embed_half(const Ctl* ctl, const __half* __restrict__ e, int d
 void embed_half(const Ctl* ctl, const void* e, int dim, float* x, hipStream_t st) {
     hipLaunchKernelGGL(k_embed_half, dim3((dim + 255) / 256), dim3(256), 0, st, ctl, reinterpret_cast<const __half*>(e), dim, x);
 }
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // out = W x with the activation (rmsnorm'ed when NORM) staged in LDS as fp32.  One wave per row
 // (row pair for SWIGLU): lane l takes the 8 halves at k = 512 j + 8 l of every wave-load j.
@@ -107,6 +107,119 @@ __global__ __launch_bounds__(512) void k_gemv_f16(const __half* __restrict__ W, 
             else out[rs] = acc[0];
         }
     }
+}
+
+// ---- batched form on the matrix cores (prompt ingestion of an fp16-attached model) ---------------
+// BASELINE config 5 asks for the fp16 path "on CDNA4 bf16/fp16 MFMA": at batch 1 a GEMV cannot use it, the
+// batched prompt pass can.  out[t][r] = W[r][:] . x_t with v_mfma_f32_16x16x32_f16: binary16 weights as at
+// batch 1, the activations of the 16..64 positions rounded to binary16 as well (the instruction takes both
+// operands in one type; at batch 1 they stay fp32), fp32 accumulation inside the MFMA.  One wave = 16 rows x
+// 16 tokens x all of K, four token tiles per workgroup sharing the weight lines through L1 -- the shape of
+// k_gemm_q8 without the per-group scales.  Parity: unpinned, like the whole contrast path; checked against
+// orc_forward_f16 (double accumulation, fp32 activations) with the activation rounding in the tolerance.
+//   A: lane l holds A[row l&15][k = 8*(l>>4) .. +7];  B the same with token l&15
+//   D: lane l, register i holds D[row 4*(l>>4) + i][token l&15]
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// (rmsnorm with weight w when given, then) fp32 -> binary16 of `rows` activation rows of n floats
+template <bool NORM>
+__global__ __launch_bounds__(256) void k_rows_half(const float* __restrict__ x, int ldx, const float* __restrict__ w, int n,
+                                                   __half* __restrict__ out) {
+    const float* xr = x + (size_t)blockIdx.x * ldx;
+    __half* o = out + (size_t)blockIdx.x * n;
+    const int lane = threadIdx.x & 63;
+    float sc = 1.0f;
+    if (NORM) {
+        const float ss = sum256_sq(xr, n, lane);          // every wave redundantly
+        sc = 1.0f / sqrtf(ss / (float)n + 1e-6f);
+    }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float v = xr[i];
+        if (NORM) v = w[i] * (sc * v);
+        o[i] = __float2half_rn(v);
+    }
+}
+void rows_half(const float* x, int ldx, const float* w, int n, int rows, void* out, hipStream_t st) {
+    if (w) hipLaunchKernelGGL(k_rows_half<true>, dim3(rows), dim3(256), 0, st, x, ldx, w, n, reinterpret_cast<__half*>(out));
+    else hipLaunchKernelGGL(k_rows_half<false>, dim3(rows), dim3(256), 0, st, x, ldx, w, n, reinterpret_cast<__half*>(out));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f16(const __half* __restrict__ W, int n, int d, const __half* __restrict__ X, int ntok,
+                                                  float* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int tt = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r0 = (int)blockIdx.x * 16;
+    const int li = lane & 15, kb = lane >> 4;
+    const int arow = r0 + li < d ? r0 + li : d - 1;
+    const int tok = tt * 16 + li < ntok ? tt * 16 + li : ntok - 1;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(W), 0, d * n * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(X), 0, ntok * n * 2, 0x00020000);
+    const int va = arow * n * 2 + 16 * kb, vb = tok * n * 2 + 16 * kb;
+    const int steps = n >> 5;                               // K = 32 per MFMA
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    v4i pa[4], pb[4], qa[4], qb[4];                          // ping / pong: four K steps computing, the next four in flight
+    auto load4 = [&](v4i (&a)[4], v4i (&b)[4], int s0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int sidx = s0 + u < steps ? s0 + u : steps - 1;
+            a[u] = __builtin_amdgcn_raw_buffer_load_b128(rW, va, sidx * 64, 0);
+            b[u] = __builtin_amdgcn_raw_buffer_load_b128(rX, vb, sidx * 64, 0);
+        }
+    };
+    auto mac4 = [&](const v4i (&a)[4], const v4i (&b)[4], int s0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (s0 + u < steps) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[u]), __builtin_bit_cast(h8, b[u]), acc, 0, 0, 0);
+        }
+    };
+    load4(pa, pb, 0);
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+        if (s0 + 4 < steps) load4(qa, qb, s0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mac4(pa, pb, s0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0 + 4 >= steps) break;
+        if (s0 + 8 < steps) load4(pa, pb, s0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        mac4(qa, qb, s0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int tokj = tt * 16 + li;
+    if (tokj >= ntok) return;
+    const int row = r0 + 4 * kb;
+    if (EPI == EPI_SWIGLU) {
+        float* o = out + (size_t)tokj * ldo + (row >> 1);
+        if (row < d) o[0] = swiglu_pair(acc[0], acc[1]);
+        if (row + 2 < d) o[1] = swiglu_pair(acc[2], acc[3]);
+    } else {
+        float* o = out + (size_t)tokj * ldo + row;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (row + i < d) o[i] = (EPI == EPI_RESID) ? o[i] + acc[i] : acc[i];
+        }
+    }
+}
+void gemm_f16(const void* W, int n, int d, const void* X, int ntok, float* out, int ldo, Epi epi, hipStream_t st) {
+    if (n % 32 || d % 2 || ntok < 1 || ntok > 64 || (long long)d * n * 2 >= (1ll << 31)) {
+        fprintf(stderr, "[q3hip] gemm_f16: bad shape (n=%d d=%d tokens=%d)\n", n, d, ntok);
+        exit(EXIT_FAILURE);
+    }
+    const __half* w = reinterpret_cast<const __half*>(W);
+    const __half* x = reinterpret_cast<const __half*>(X);
+    const dim3 grid((d + 15) / 16), block(64 * ((ntok + 15) / 16));
+    if (epi == EPI_STORE) hipLaunchKernelGGL(k_gemm_f16<EPI_STORE>, grid, block, 0, st, w, n, d, x, ntok, out, ldo);
+    else if (epi == EPI_RESID) hipLaunchKernelGGL(k_gemm_f16<EPI_RESID>, grid, block, 0, st, w, n, d, x, ntok, out, ldo);
+    else hipLaunchKernelGGL(k_gemm_f16<EPI_SWIGLU>, grid, block, 0, st, w, n, d, x, ntok, out, ldo);
+}
+
+// x rows of a prompt chunk from the binary16 embedding table
+__global__ void k_embed_rows_half(const int* __restrict__ tokens, const __half* __restrict__ e, int dim, float* __restrict__ x, int ldx) {
+    const size_t base = (size_t)tokens[blockIdx.x] * dim;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) x[(size_t)blockIdx.x * ldx + i] = __half2float(e[base + i]);
+}
+void embed_rows_half(const int* tokens, int ntok, const void* e, int dim, float* x, int ldx, hipStream_t st) {
+    hipLaunchKernelGGL(k_embed_rows_half, dim3(ntok), dim3(256), 0, st, tokens, reinterpret_cast<const __half*>(e), dim, x, ldx);
 }
 
 void gemv_f16(const void* W, int n, int d, const float* x, const float* nw, float* out, Epi epi, hipStream_t st) {

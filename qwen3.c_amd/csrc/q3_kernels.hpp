@@ -58,7 +58,7 @@ struct Attn {
     // ctl[z], qkv + z*zs_qkv, cs + z*zs_cs, oq + z*zs_oq, os + z*zs_os, part + z*zs_part, tickets + z*zs_tickets.
     // Their k/v rows must already be in the cache (kv_append): a later position reads an earlier one's.
     int nz;              // 0 or 1 = a single position
-    int zs_qkv, zs_cs, zs_oq, zs_os, zs_tickets;
+    int zs_qkv, zs_cs, zs_oq, zs_os, zs_tickets, zs_of;
     size_t zs_part;
 };
 // k (head norm + RoPE) and v of `ntok` consecutive positions into the cache (reference forward.c:270-286),
@@ -116,6 +116,11 @@ void embed_half(const Ctl* ctl, const void* e, int dim, float* x, hipStream_t st
 // EPI_SWIGLU: rows interleaved (gate, up) -> out[d/2].  Only the three combinations a layer uses exist:
 // (nw, STORE), (nw, SWIGLU), (null, RESID).
 void gemv_f16(const void* W, int n, int d, const float* x, const float* nw, float* out, Epi epi, hipStream_t st);
+// batched form on v_mfma_f32_16x16x32_f16 (prompt ingestion of an fp16-attached model): activation rows to
+// binary16 ((rmsnorm with w when given) then round), out[t][r] (+)= W[r][:] . X[t][:] for ntok <= 64
+void rows_half(const float* x, int ldx, const float* w, int n, int rows, void* out, hipStream_t st);
+void gemm_f16(const void* W, int n, int d, const void* X, int ntok, float* out, int ldo, Epi epi, hipStream_t st);
+void embed_rows_half(const int* tokens, int ntok, const void* e, int dim, float* x, int ldx, hipStream_t st);
 
 // ---- device-side sampling (q3_sample.hip) -----------------------------------------------
 #define Q3_SAMPLE_MAX_CHUNKS 1024

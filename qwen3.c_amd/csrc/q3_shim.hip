@@ -144,6 +144,8 @@ struct Dev {
     int* pf_tokens = nullptr;
     q3k::Ctl* pf_ctl = nullptr;
     float *pf_cs = nullptr, *pf_x = nullptr, *pf_qkv = nullptr, *pf_h = nullptr, *pf_as = nullptr, *pf_xs = nullptr;
+    uint16_t* pf_xh = nullptr;    // fp16 attach: activation rows rounded to binary16 (MFMA operand)
+    float* pf_attf = nullptr;     // fp16 attach: fp32 head outputs of the chunk [B][P]
     float* pf_part = nullptr;     // chunk partials of 16 positions
     unsigned* pf_tickets = nullptr;
     int8_t *pf_aq = nullptr, *pf_xq = nullptr;
@@ -1111,6 +1113,10 @@ void ensure_prefill(Dev* d) {
     d->pf_part = dalloc<float>(d, (size_t)B * d->H * d->max_chunks * (d->hd + 2));
     d->pf_tickets = dalloc<unsigned>(d, (size_t)B * d->KV);
     HIPCHK(hipMemsetAsync(d->pf_tickets, 0, (size_t)B * d->KV * sizeof(unsigned), d->st));
+    if (d->fp16) {
+        d->pf_xh = dalloc<uint16_t>(d, (size_t)B * wide);
+        d->pf_attf = dalloc<float>(d, (size_t)B * d->P);
+    }
     d->pf_ready = true;
 }
 
@@ -1154,6 +1160,47 @@ void prefill_chunk(Dev* d, const int* tokens, int bc, int pos0) {
         q3k::gemm_q8(L.dn_q, L.dn_s, d->hid, d->dim, d->pf_xq, d->pf_xs, bc, d->pf_x, d->dim, q3k::EPI_RESID, d->st);
     }
 }
+// the same chunk on an fp16-attached model (BASELINE config 5 in its batched, matrix-core form): binary16
+// weights x binary16-rounded activation rows on v_mfma_f32_16x16x32_f16, fp32 accumulation; attention is the
+// shared fp32 kernel.  No reference arithmetic to match (parity unpinned): checked against orc_forward_f16.
+void prefill_chunk_f16(Dev* d, const int* tokens, int bc, int pos0) {
+    const int QKV = d->P + 2 * d->KVD;
+    HIPCHK(hipMemcpyAsync(d->pf_tokens, tokens, (size_t)bc * sizeof(int), hipMemcpyHostToDevice, d->st));
+    q3k::prefill_begin(d->pf_tokens, bc, pos0, nullptr, nullptr, d->dim, d->pf_x, d->dim, d->rope, d->hd, d->pf_cs,
+                       d->pf_ctl, d->st);
+    q3k::embed_rows_half(d->pf_tokens, bc, d->emb_h, d->dim, d->pf_x, d->dim, d->st);
+    for (int l = d->l0; l < d->l1; l++) {
+        const LayerDev& L = d->layers[l];
+        q3k::rows_half(d->pf_x, d->dim, L.att_nw, d->dim, bc, d->pf_xh, d->st);
+        q3k::gemm_f16(L.qkv_h, d->dim, QKV, d->pf_xh, bc, d->pf_qkv, QKV, q3k::EPI_STORE, d->st);
+        {
+            q3k::Attn a = attn_args(d, l, 0);
+            a.ctl = d->pf_ctl; a.qkv = d->pf_qkv; a.cs = d->pf_cs; a.oq = d->pf_aq; a.os = d->pf_as; a.of = d->pf_attf;
+            a.part = d->pf_part; a.tickets = d->pf_tickets;
+            a.zs_qkv = QKV; a.zs_cs = d->hd; a.zs_oq = d->P; a.zs_os = d->P / 64; a.zs_tickets = d->KV; a.zs_of = d->P;
+            a.zs_part = (size_t)d->H * d->max_chunks * (d->hd + 2);
+            q3k::kv_append(a, bc, d->st);
+            for (int t0 = 0; t0 < bc;) {
+                const q3k::AttMode mode = q3k::attn_mode(pos0 + t0);
+                int t1 = t0 + 1;
+                while (t1 < bc && q3k::attn_mode(pos0 + t1) == mode) t1++;
+                q3k::Attn b = a;
+                b.ctl += t0; b.qkv += (size_t)t0 * a.zs_qkv; b.cs += (size_t)t0 * a.zs_cs; b.oq += (size_t)t0 * a.zs_oq;
+                b.os += (size_t)t0 * a.zs_os; b.part += (size_t)t0 * a.zs_part; b.tickets += (size_t)t0 * a.zs_tickets;
+                b.of += (size_t)t0 * a.zs_of;
+                b.nz = t1 - t0;
+                q3k::attn(b, d->chunk_slots, mode, d->st);
+                t0 = t1;
+            }
+        }
+        q3k::rows_half(d->pf_attf, d->P, nullptr, d->P, bc, d->pf_xh, d->st);
+        q3k::gemm_f16(L.wo_h, d->P, d->dim, d->pf_xh, bc, d->pf_x, d->dim, q3k::EPI_RESID, d->st);
+        q3k::rows_half(d->pf_x, d->dim, L.ffn_nw, d->dim, bc, d->pf_xh, d->st);
+        q3k::gemm_f16(L.gu_h, d->dim, 2 * d->hid, d->pf_xh, bc, d->pf_h, d->hid, q3k::EPI_SWIGLU, d->st);
+        q3k::rows_half(d->pf_h, d->hid, nullptr, d->hid, bc, d->pf_xh, d->st);
+        q3k::gemm_f16(L.dn_h, d->hid, d->dim, d->pf_xh, bc, d->pf_x, d->dim, q3k::EPI_RESID, d->st);
+    }
+}
 }  // namespace
 
 /* Prompt ingestion: what completion()'s prompt loop (src/completion.c:57-66) does with n calls of
@@ -1162,7 +1209,6 @@ void prefill_chunk(Dev* d, const int* tokens, int bc, int pos0) {
 float* q3_prefill(Model* m, const int* tokens, int n, int pos0) {
     Dev* d = attach(m);
     if (d->world > 1) Q3_DIE("q3_prefill: single-GPU models only");
-    if (d->fp16) Q3_DIE("q3_prefill: the fp16 contrast path has no batched form");
     if (!tokens || n < 1) Q3_DIE("q3_prefill: empty prompt");
     if (pos0 < 0 || pos0 + n > d->seq) Q3_DIE("q3_prefill: positions [%d,%d) outside the context window [0,%d)", pos0, pos0 + n, d->seq);
     for (int i = 0; i < n; i++) {
@@ -1172,7 +1218,8 @@ float* q3_prefill(Model* m, const int* tokens, int n, int pos0) {
     ensure_prefill(d);
     for (int c0 = 0; c0 < n; c0 += Q3_PF_CHUNK) {
         const int bc = n - c0 < Q3_PF_CHUNK ? n - c0 : Q3_PF_CHUNK;
-        prefill_chunk(d, tokens + c0, bc, pos0 + c0);
+        if (d->fp16) prefill_chunk_f16(d, tokens + c0, bc, pos0 + c0);
+        else prefill_chunk(d, tokens + c0, bc, pos0 + c0);
         if (c0 + bc < n) HIPCHK(hipStreamSynchronize(d->st));      // the token upload buffer is reused
     }
     const int last = (n - 1) % Q3_PF_CHUNK;

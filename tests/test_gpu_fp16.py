@@ -32,3 +32,35 @@ def test_fp16_path_matches_double_precision_restatement(hip, host, orc, name, st
     assert worst <= 2e-4, worst
     assert differs                                              # it really is another arithmetic than the Q8_0 path
     hip.q3_model_close(mg); hip.q3_model_close(mq); host.q3_model_close(mo)
+
+
+@pytest.mark.parametrize("name,n", [("tiny", 40), ("small", 70), ("4Bmini", 80)])
+def test_fp16_prefill_on_the_matrix_cores(hip, host, orc, name, n):
+    """BASELINE config 5 in its batched form: q3_prefill of an fp16-attached model runs the four GEMMs of a layer
+    on v_mfma_f32_16x16x32_f16 (binary16 weights x binary16-rounded activations, fp32 accumulate).  Parity
+    unpinned (nothing in the reference does this); the checker is orc_forward_f16 fed token by token -- binary16
+    weights, fp32 activations, double accumulation -- so the bar carries the activation rounding (2^-11 relative
+    per element, averaged over the dot products and the layers)."""
+    import ctypes as C
+    path = os.path.join(Q.tmp_dir(), f"{name}.bin")
+    spec = Q.synth(name, path)
+    n = min(n, spec.seq_len - 4)
+    mg = hip.q3_model_open(path.encode(), 0, 0)
+    assert hip.q3_device_attach_fp16(mg) == 0
+    mo = host.q3_model_open(path.encode(), 0, 1)
+    orc.orc_set_threads(8)
+    prompt = np.random.default_rng(17).integers(0, spec.vocab_size, size=n).astype(np.int32)
+    arr = (C.c_int * n)(*[int(t) for t in prompt])
+    lg = Q.logits_array(mg, hip.q3_prefill(mg, arr, n, 0))
+    for pos in range(n):
+        lo = Q.logits_array(mo, orc.orc_forward_f16(mo, int(prompt[pos]), pos))
+    err_prefill = float(np.abs(lg - lo).max() / np.abs(lo).max())
+    # a decode step on top of the cache the batched pass left
+    tok = int(lo.argmax())
+    lg2 = Q.logits_array(mg, hip.forward(mg, tok, n))
+    lo2 = Q.logits_array(mo, orc.orc_forward_f16(mo, tok, n))
+    err_next = float(np.abs(lg2 - lo2).max() / np.abs(lo2).max())
+    orc.orc_set_threads(1)
+    Q.record_parity(f"fp16_mfma_prefill_{name}", {"prompt": n, "rel_err_after_prompt": err_prefill, "rel_err_next_decode_step": err_next})
+    assert np.isfinite(lg).all() and err_prefill <= 2e-2 and err_next <= 2e-2, (err_prefill, err_next)
+    hip.q3_model_close(mg); host.q3_model_close(mo)
