@@ -14,7 +14,7 @@
  *   ForwardState  <-> reference include/model.h:92-117
  *   Model         <-> reference include/model.h:123-129
  *
- * tests/test_abi.py checks sizeof/offsetof of every field against the numbers
+ * tests/test_abi_and_symbols.py checks sizeof/offsetof of every field against the numbers
  * the reference headers produce with the same compiler.
  */
 #ifndef Q3_ABI_H

@@ -180,7 +180,6 @@ int q3_prof_get(Model* m, Q3ProfEntry* out, int max_entries);
 /* Mean duration of the launches of kernel class `name` by the device clock read inside the
  * kernel (first workgroup in .. last workgroup out; GEMV classes only), in microseconds. */
 double q3_prof_device_us(Model* m, const char* name);
-double q3_prof_overhead_us(Model* m);   /* reserved, returns 0 */
 
 /* ---- multi-GPU layer pipeline (one process per GPU) --------------------
  * The reference has no multi-device path; this is the layer pipeline

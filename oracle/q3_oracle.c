@@ -10,7 +10,7 @@
  *
  *   ORC_REF  (0)  the reference's arithmetic in the reference's order, one
  *                 thread: every loop below cites the reference lines it
- *                 restates.  PINNED: tests/test_oracle_vs_reference.py checks
+ *                 restates.  PINNED: tests/test_oracle.py checks
  *                 it bit-for-bit against the reference itself compiled from
  *                 /root/reference (oracle/_ref/libqwen3_ref.so, -O2 -DNDEBUG,
  *                 OMP_NUM_THREADS=1) and tests/golden/ holds logits captured

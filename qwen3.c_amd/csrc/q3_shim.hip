@@ -1436,11 +1436,6 @@ double q3_prof_device_us(Model* m, const char* name) {
     return 0.0;
 }
 
-double q3_prof_overhead_us(Model* m) {
-    (void)m;
-    return 0.0;
-}
-
 void q3_prof_reset(Model* m) {
     Dev* d = attach(m);
     for (auto& s : d->prof_slots) {

@@ -199,8 +199,6 @@ def hip_lib():
         lib.q3_prof_reset.argtypes = [ModelP]
         lib.q3_prof_device_us.restype = C.c_double
         lib.q3_prof_device_us.argtypes = [ModelP, C.c_char_p]
-        lib.q3_prof_overhead_us.restype = C.c_double
-        lib.q3_prof_overhead_us.argtypes = [ModelP]
         lib.q3_prof_get.restype = C.c_int
         lib.q3_prof_get.argtypes = [ModelP, C.POINTER(ProfEntry), C.c_int]
         lib.q3_pipeline_unique_id.restype = C.c_int
