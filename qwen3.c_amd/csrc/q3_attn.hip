@@ -29,12 +29,14 @@ namespace q3k {
 #define Q3_MAXG 8   // max query heads per kv head
 
 #ifdef Q3_ATTN_STAMPS
-#define STAMP(i) do { if (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.stamps[2*(i)] = __builtin_amdgcn_s_memrealtime(); a.stamps[2*(i)+1] = __builtin_amdgcn_s_memtime(); } } while (0)
+// every workgroup of grid layer 0 leaves eight device-clock marks: stamps[8 * workgroup + i]
+#define STAMP(i) do { if (a.stamps && blockIdx.z == 0 && threadIdx.x == 0) a.stamps[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
 
 typedef __attribute__((address_space(1))) unsigned g_u32;
+
 
 // write-through 8-byte store / cache-bypassing loads for data handed to another workgroup
 // inside the launch
@@ -513,17 +515,19 @@ __global__ __launch_bounds__(64) void k_attn_merge(Attn a_in) {
     constexpr int GPH = HD / 64;                // quantisation groups per head
     const int h = blockIdx.x / GPH, grp = blockIdx.x % GPH;
     const int lane = threadIdx.x;
-    const int nchunks = a.ctl->pos / Q3_ATT_CHUNK + 1;
     const float* base = a.part + (size_t)h * a.max_chunks * ST;
     const int d = grp * 64 + lane;
     // Everything the first 64 chunks need -- their (m_c, l_c) pairs, one per lane, and this lane's
-    // value of each O_c -- is requested in ONE burst: the usual context (<= 4096 positions) costs a
-    // single memory round trip.  Longer contexts walk further blocks of 64 chunks.
-    float2 ml0 = make_float2(-3.0e38f, 0.0f);
-    if (lane < nchunks) ml0 = *reinterpret_cast<const float2*>(base + (size_t)lane * ST + HD);
+    // value of each O_c -- is requested in ONE burst together with the position itself (rows beyond
+    // the last chunk exist in the buffer; what they hold is masked below): the usual context
+    // (<= 4096 positions) costs a single memory round trip.  Longer contexts walk further blocks.
+    const int rmax = a.max_chunks - 1;
+    float2 ml0 = *reinterpret_cast<const float2*>(base + (size_t)(lane < rmax ? lane : rmax) * ST + HD);
     float o0[64];
 #pragma unroll
-    for (int k = 0; k < 64; k++) o0[k] = base[(size_t)(k < nchunks ? k : nchunks - 1) * ST + d];
+    for (int k = 0; k < 64; k++) o0[k] = base[(size_t)(k < rmax ? k : rmax) * ST + d];
+    const int nchunks = a.ctl->pos / Q3_ATT_CHUNK + 1;
+    if (lane >= nchunks) ml0 = make_float2(-3.0e38f, 0.0f);
     float M = wave_max(ml0.x);
     for (int c0 = 64; c0 < nchunks; c0 += 64) {
         const int c = c0 + lane;

@@ -81,12 +81,22 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float sum256_sq(const float* __restrict__ x, int n, int lane) {
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    for (int i = 4 * lane; i < n; i += 256) {
-        const float4 v = x4[i >> 2];
-        c0 = c0 + v.x * v.x;
-        c1 = c1 + v.y * v.y;
-        c2 = c2 + v.z * v.z;
-        c3 = c3 + v.w * v.w;
+    // eight loads in flight per round (a load per iteration costs a memory round trip each); slots
+    // past the end hold zeros, and c + 0*0 == c exactly
+    for (int i0 = 4 * lane; i0 < n; i0 += 8 * 256) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + 256 * k;
+            v[k] = i < n ? x4[i >> 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            c0 = c0 + v[k].x * v[k].x;
+            c1 = c1 + v[k].y * v[k].y;
+            c2 = c2 + v[k].z * v[k].z;
+            c3 = c3 + v[k].w * v[k].w;
+        }
     }
     return bfly64((c0 + c1) + (c2 + c3));
 }

@@ -3,7 +3,7 @@
 // token, and the Q8_0 product runs on the matrix cores.
 //
 //   k_rows_quantize   the GEMV prologue (rmsnorm + q8_quantize, or q8_quantize alone) for B
-//                     activation rows at once: one workgroup per row
+//                     activation rows at once: a workgroup per row and 1024-element span
 //   k_gemm_q8         out[t][r] = W[r][:] . x_t for 16 rows x 16 tokens per wave with
 //                     v_mfma_i32_16x16x64_i8: K = 64 is exactly one Q8_0 group, so ONE MFMA
 //                     yields the exact int32 group dots of 256 (row, token) pairs; each is then
@@ -19,6 +19,7 @@
 // up with 4 consecutive output rows of ONE token: one 16-byte store.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "q3_device.hpp"
 #include "q3_kernels.hpp"
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void k_rows_quantize(const float* __restrict__
         const float ss = sum256_sq(xr, n, lane);          // every wave redundantly
         sc = 1.0f / sqrtf(ss / (float)n + 1e-6f);
     }
-    for (int base = wave * 256; base < n; base += 4 * 256) {
+    for (int base = ((int)blockIdx.y * 4 + wave) * 256; base < n; base += (int)gridDim.y * 4 * 256) {
         const int i = base + 4 * lane;
         const bool act = i < n;
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -65,8 +66,10 @@ __global__ __launch_bounds__(256) void k_rows_quantize(const float* __restrict__
 }
 
 void rows_quantize(const float* x, int ldx, const float* w, int n, int rows, int8_t* q, float* s, hipStream_t st) {
-    if (w) hipLaunchKernelGGL(k_rows_quantize<true>, dim3(rows), dim3(256), 0, st, x, ldx, w, n, q, s);
-    else hipLaunchKernelGGL(k_rows_quantize<false>, dim3(rows), dim3(256), 0, st, x, ldx, w, n, q, s);
+    // a row is split over up to 8 workgroups of 1024 elements (each recomputes the row's sum of squares)
+    const int split = (n + 1023) / 1024 < 8 ? (n + 1023) / 1024 : 8;
+    if (w) hipLaunchKernelGGL(k_rows_quantize<true>, dim3(rows, split), dim3(256), 0, st, x, ldx, w, n, q, s);
+    else hipLaunchKernelGGL(k_rows_quantize<false>, dim3(rows, split), dim3(256), 0, st, x, ldx, w, n, q, s);
 }
 
 // ---- Q8_0 GEMM on int8 MFMA ----------------------------------------------------------------
@@ -216,6 +219,195 @@ __global__ __launch_bounds__(256) void k_gemm_q8(const int8_t* __restrict__ W, c
     }
 }
 
+// ---- the same GEMM with both operands staged through LDS in whole 128-byte lines ---------------
+// k_gemm_q8 above makes every lane gather its own 16-byte operand slices: per MFMA the CU's vector
+// memory path touches 32 half lines, and that, not HBM or the VALU, is what its time follows.  Here a
+// workgroup owns 16*RT rows x 64 tokens and walks K in slabs of 512 bytes (8 groups) with its eight
+// waves in two roles:
+//   waves 4..7  FETCH.  Every thread requests 16-byte pieces that are CONSECUTIVE across the lanes (a
+//               wave-load = two rows x 512 B = eight whole lines), three slabs ahead in three register
+//               sets, and parks a landed slab in one of two LDS buffers whose 16-byte slots are
+//               XOR-swizzled by the row, so the operand reads of the 16 rows (or tokens) of a k-block
+//               hit 16 different bank groups.  A CU takes in only ~40 KB of requests at once, so these
+//               waves spend their life in the issue stage -- which is why they do nothing else.
+//   waves 0..3  MULTIPLY.  Wave t owns token tile t and all RT row tiles: per group one activation
+//               read, RT weight reads, RT MFMAs, and the scale-accumulate into its 16 column sums per
+//               output (64*RT registers).  They never issue a global load, so they never stall in it.
+// One barrier per slab: it says "slab s is in LDS and slab s-1 has been consumed" (slab s+1 goes into
+// the buffer slab s-1 occupied).  The weight slab is shared by the four token tiles, the activation
+// slab by the RT row tiles; the per-group scales ride along ([group][row] in LDS: a lane's four row
+// scales are one 16-byte read).  Arithmetic per (row, token): exactly k_gemm_q8's -- the group dots
+// of one MFMA, ((float)dot * ws) * xs, added to column (g & 15) in ascending g; the butterfly at the
+// end.  Needs n % 512 == 0 (all Qwen3 shapes; fixtures with narrower rows take k_gemm_q8).
+template <int RT> struct GemmSlab {       // what one fetching thread holds of a slab
+    v4i a[2 * RT];
+    v4i b[8];
+    float ws;
+    float xs[2];
+};
+
+__device__ __forceinline__ int slab_off(int row, int piece) {       // byte offset of (row, 16-byte piece) in an LDS slab
+    return row * 512 + ((((piece ^ row) & 15) | (piece & 16)) << 4);
+}
+
+template <int EPI, int RT>
+__global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ W, const float* __restrict__ S, int n,
+                                                     int d, const int8_t* __restrict__ xq,
+                                                     const float* __restrict__ xs, int ntok,
+                                                     float* __restrict__ out, int ldo) {
+    constexpr int R = 16 * RT;
+    constexpr int A_BYTES = R * 512, B_BYTES = 64 * 512, WS_BYTES = 8 * R * 4, XS_BYTES = 8 * 64 * 4;
+    constexpr int OFF_B = A_BYTES, OFF_WS = A_BYTES + B_BYTES, OFF_XS = OFF_WS + WS_BYTES;
+    constexpr int STAGE = OFF_XS + XS_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = (int)blockIdx.x * R;
+    const int ng = n >> 6, nslab = n >> 9;
+    const int ntok16 = (ntok + 15) & ~15;
+
+    if (wave >= 4) {
+        // ---------------------------------------------------------------- FETCH
+        // rows >= d and tokens >= ntok lie beyond the buffer ranges: they read as zero and are dropped at the store
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(W), 0, d * n, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S), 0, d * ng * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(xq), 0, ntok * n, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rXS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs), 0, ntok * ng * 4, 0x00020000);
+        const int t = tid - 256;
+        const int prow = t >> 5, piece = t & 31;                 // this thread's (row, piece) of a slab; +8 rows per further load
+        const int va = (r0 + prow) * n + piece * 16;
+        const int vb = prow * n + piece * 16;
+        const int vws = ((r0 + (t >> 3)) * ng + (t & 7)) * 4;    // threads < 8*R
+        const int vxs = ((t >> 3) * ng + (t & 7)) * 4;
+        auto fetch = [&](GemmSlab<RT>& r, int sl) {              // slab sl (wave-uniform)
+#pragma unroll
+            for (int k = 0; k < 2 * RT; k++) r.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rW, va + k * 8 * n, sl * 512, 0);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (prow + 8 * k < ntok16)                        // wave-uniform: a wave covers two rows, ntok16 is a multiple of 16
+                    r.b[k] = __builtin_amdgcn_raw_buffer_load_b128(rX, vb + k * 8 * n, sl * 512, 0);
+            }
+            if (t < 8 * R) r.ws = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vws, sl * 32, 0));
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                r.xs[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rXS, vxs + k * 32 * ng * 4, sl * 32, 0));
+        };
+        auto park = [&](const GemmSlab<RT>& r, int buf) {        // registers -> LDS buffer `buf`
+            unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+            for (int k = 0; k < 2 * RT; k++) *reinterpret_cast<v4i*>(base + slab_off(prow + 8 * k, piece)) = r.a[k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (prow + 8 * k < ntok16) *reinterpret_cast<v4i*>(base + OFF_B + slab_off(prow + 8 * k, piece)) = r.b[k];
+            }
+            if (t < 8 * R) reinterpret_cast<float*>(base + OFF_WS)[(t & 7) * R + (t >> 3)] = r.ws;
+#pragma unroll
+            for (int k = 0; k < 2; k++) reinterpret_cast<float*>(base + OFF_XS)[(t & 7) * 64 + (t >> 3) + 32 * k] = r.xs[k];
+        };
+        GemmSlab<RT> S0, S1, S2;                                 // three slabs in flight
+        fetch(S0, 0);
+        if (nslab > 1) fetch(S1, 1);
+        if (nslab > 2) fetch(S2, 2);
+        for (int sl = 0; sl < nslab; sl += 3) {
+            park(S0, sl & 1);
+            if (sl + 3 < nslab) fetch(S0, sl + 3);
+            __syncthreads();
+            if (sl + 1 >= nslab) break;
+            park(S1, (sl + 1) & 1);
+            if (sl + 4 < nslab) fetch(S1, sl + 4);
+            __syncthreads();
+            if (sl + 2 >= nslab) break;
+            park(S2, sl & 1);
+            if (sl + 5 < nslab) fetch(S2, sl + 5);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- MULTIPLY
+    const int tt = wave;
+    const int li = lane & 15, kb = lane >> 4;
+    const int brow = tt * 16 + li;
+    const bool live = tt * 16 < ntok;                        // wave-uniform: this wave's token tile exists
+    float col[RT][16][4];                                    // [row tile][SUM16 column][output register]
+#pragma unroll
+    for (int r = 0; r < RT; r++)
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[r][c][i] = 0.0f;
+
+    auto compute = [&](auto par) {                           // slab in LDS buffer PAR (= slab index & 1): columns 8*PAR ..
+        constexpr int PAR = decltype(par)::value;
+        const unsigned char* base = smem + PAR * STAGE;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const v4i b = *reinterpret_cast<const v4i*>(base + OFF_B + slab_off(brow, 4 * g + kb));
+            const float sx = *reinterpret_cast<const float*>(base + OFF_XS + (g * 64 + brow) * 4);
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                const v4i a = *reinterpret_cast<const v4i*>(base + slab_off(r * 16 + li, 4 * g + kb));
+                const float4 sw = *reinterpret_cast<const float4*>(base + OFF_WS + (g * R + r * 16 + 4 * kb) * 4);
+                const v4i32 zero = {0, 0, 0, 0};
+                const v4i32 dd = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, zero, 0, 0, 0);
+                const float swv[4] = {sw.x, sw.y, sw.z, sw.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float p = ((float)dd[i] * swv[i]) * sx;
+                    col[r][8 * PAR + g][i] = col[r][8 * PAR + g][i] + p;
+                }
+            }
+        }
+    };
+    for (int sl = 0; sl < nslab; sl += 2) {
+        __syncthreads();                                     // slab sl is in buffer 0
+        if (live) compute(std::integral_constant<int, 0>());
+        if (sl + 1 >= nslab) break;
+        __syncthreads();                                     // slab sl+1 is in buffer 1
+        if (live) compute(std::integral_constant<int, 1>());
+    }
+
+    const int tokj = tt * 16 + li;
+    if (tokj >= ntok) return;
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+        float res[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float t8[8], t4[4], t2[2];
+#pragma unroll
+            for (int c = 0; c < 8; c++) t8[c] = col[r][c][i] + col[r][c + 8][i];
+#pragma unroll
+            for (int c = 0; c < 4; c++) t4[c] = t8[c] + t8[c + 4];
+#pragma unroll
+            for (int c = 0; c < 2; c++) t2[c] = t4[c] + t4[c + 2];
+            res[i] = t2[0] + t2[1];
+        }
+        const int row = r0 + r * 16 + 4 * kb;
+        if (EPI == EPI_SWIGLU) {
+            float* o = out + (size_t)tokj * ldo + (row >> 1);
+            if (row < d) o[0] = swiglu_pair(res[0], res[1]);
+            if (row + 2 < d) o[1] = swiglu_pair(res[2], res[3]);
+        } else {
+            float* o = out + (size_t)tokj * ldo + row;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (row + i < d) o[i] = (EPI == EPI_RESID) ? o[i] + res[i] : res[i];
+            }
+        }
+    }
+}
+
+template <int RT>
+static void launch_gemm_lds(const int8_t* W, const float* S, int n, int d, const int8_t* xq, const float* xs, int ntok,
+                            float* out, int ldo, Epi epi, hipStream_t st) {
+    const dim3 grid((d + 16 * RT - 1) / (16 * RT)), block(512);
+    if (epi == EPI_STORE) hipLaunchKernelGGL((k_gemm_q8_lds<EPI_STORE, RT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+    else if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_q8_lds<EPI_RESID, RT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+    else hipLaunchKernelGGL((k_gemm_q8_lds<EPI_SWIGLU, RT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+}
+
 template <bool AL4>
 static void launch_gemm(const int8_t* W, const float* S, int n, int d, const int8_t* xq, const float* xs, int ntok,
                         float* out, int ldo, Epi epi, hipStream_t st) {
@@ -229,6 +421,13 @@ void gemm_q8(const int8_t* W, const float* S, int n, int d, const int8_t* xq, co
     if (n % 64 || d % 2 || ntok < 1 || ntok > 64 || (long long)d * n >= (1ll << 31)) {
         fprintf(stderr, "[q3hip] gemm_q8: bad shape (n=%d d=%d tokens=%d)\n", n, d, ntok);
         exit(EXIT_FAILURE);
+    }
+    static const int force_gather = getenv("Q3_GEMM_GATHER") ? atoi(getenv("Q3_GEMM_GATHER")) : 0;   // diagnosis: the k_gemm_q8 path
+    if (n % 512 == 0 && !force_gather) {
+        // enough 32-row tiles to fill the chip twice over -> the wider tile (half the activation traffic)
+        if (d >= 2 * 256 * 32) launch_gemm_lds<2>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
+        else launch_gemm_lds<1>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
+        return;
     }
     if ((n >> 6) % 4 == 0) launch_gemm<true>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);
     else launch_gemm<false>(W, S, n, d, xq, xs, ntok, out, ldo, epi, st);

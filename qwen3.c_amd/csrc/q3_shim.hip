@@ -1149,7 +1149,9 @@ void prefill_chunk(Dev* d, const int* tokens, int bc, int pos0) {
                 b.ctl += t0; b.qkv += (size_t)t0 * a.zs_qkv; b.cs += (size_t)t0 * a.zs_cs; b.oq += (size_t)t0 * a.zs_oq;
                 b.os += (size_t)t0 * a.zs_os; b.part += (size_t)t0 * a.zs_part; b.tickets += (size_t)t0 * a.zs_tickets;
                 b.nz = t1 - t0;
-                q3k::attn(b, d->chunk_slots, mode, d->st);
+                // the positions are known here (no graph to keep in shape): only the chunk slots the last one needs
+                const int need = (pos0 + t1 - 1) / Q3_ATT_CHUNK + 1;
+                q3k::attn(b, need < d->chunk_slots ? need : d->chunk_slots, mode, d->st);
                 t0 = t1;
             }
         }
@@ -1189,7 +1191,9 @@ void prefill_chunk_f16(Dev* d, const int* tokens, int bc, int pos0) {
                 b.os += (size_t)t0 * a.zs_os; b.part += (size_t)t0 * a.zs_part; b.tickets += (size_t)t0 * a.zs_tickets;
                 b.of += (size_t)t0 * a.zs_of;
                 b.nz = t1 - t0;
-                q3k::attn(b, d->chunk_slots, mode, d->st);
+                // the positions are known here (no graph to keep in shape): only the chunk slots the last one needs
+                const int need = (pos0 + t1 - 1) / Q3_ATT_CHUNK + 1;
+                q3k::attn(b, need < d->chunk_slots ? need : d->chunk_slots, mode, d->st);
                 t0 = t1;
             }
         }

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n,d,ntok", [(64, 16, 1), (128, 48, 3), (320, 64, 16), (2560, 96, 16), (1024, 34, 7),
-                                      (9728, 32, 16), (4096, 2560, 5), (2560, 64, 17), (320, 48, 32), (9728, 34, 29), (2560, 64, 64), (1024, 48, 49)])
+                                      (9728, 32, 16), (4096, 2560, 5), (2560, 64, 17), (320, 48, 32), (9728, 34, 29), (2560, 64, 64), (1024, 48, 49),
+                                      # the LDS-staged kernel: one slab, an odd number of slabs, the 32-row tile (d >= 16384) with ragged rows
+                                      (512, 16, 1), (1536, 40, 20), (512, 16400, 33), (1024, 16418, 64)])
 def test_mfma_gemm_equals_gemv_per_token(hip, orc, n, d, ntok):
     """asymmetric random data: any slip in the MFMA operand or result maps shows up as a wrong row or token"""
     rng = np.random.default_rng(n + 3 * d + ntok)
