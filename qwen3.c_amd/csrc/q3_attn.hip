@@ -490,6 +490,244 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
     STAMP(7);
 }
 
+// ---- batched prompt ingestion: zb consecutive positions share ONE staged K/V tile --------------
+// k_attn with one grid layer per position stages the same 64 KB tile once per position: at 256 cached
+// positions a 64-position pass pulls 134 MB through the CUs for 2 MB of cache.  Here a workgroup
+// (kv head, chunk slot, block of zb positions) stages the tile once -- the k/v rows of the pass are
+// already in the cache (kv_append) -- and walks its positions with it: wave = query head as in k_attn,
+// the scores / softmax / PV code is k_attn's operation for operation (q3_numerics.h "attention"), so
+// are the partials, the tickets and the merge.  Positions must ascend with z (prefill passes do).
+template <int HD, int HPW>
+__global__ __launch_bounds__(256, 2) void k_attn_block(Attn a, int multi, int zb) {
+    constexpr int L4 = HD / 4;
+    constexpr int CH = Q3_ATT_CHUNK;
+    constexpr int NLD = CH * L4 / 256;
+    __shared__ __attribute__((aligned(16))) float Ks[CH * HD];
+    __shared__ __attribute__((aligned(16))) float Vs[CH * HD];
+    __shared__ int last_flags[8];
+
+    const int g = blockIdx.x;
+    const int kv_mul = a.n_heads / a.n_kv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int half = lane >> 5, l = lane & 31;
+    const bool act = l < L4;
+    const size_t cbase = (size_t)g * a.seq_len * HD;
+    const int nz = a.nz > 1 ? a.nz : 1;
+    const int z0 = (int)blockIdx.z * zb;
+    const int z1 = z0 + zb < nz ? z0 + zb : nz;
+    const int pos_last = a.ctl[z1 - 1].pos;
+    const float root = sqrtf((float)HD);
+
+    for (int c = blockIdx.y; c * CH <= pos_last; c += gridDim.y) {
+        const int t0 = c * CH;
+        // ---- the tile: all 64 rows (rows beyond a position's own are masked per position below)
+        {
+            float4 kt[NLD], vt[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const int idx = tid + k * 256;
+                const int t = idx / L4, l4 = idx - t * L4;
+                kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const int idx = tid + k * 256;
+                const int t = idx / L4, l4 = idx - t * L4;
+                vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(t0 + t) * HD + 4 * l4);
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const int idx = tid + k * 256;
+                const int t = idx / L4, l4 = idx - t * L4;
+                *reinterpret_cast<float4*>(Ks + t * HD + 4 * l4) = kt[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const int idx = tid + k * 256;
+                const int t = idx / L4, l4 = idx - t * L4;
+                *reinterpret_cast<float4*>(Vs + t * HD + 4 * l4) = vt[k];
+            }
+        }
+        __syncthreads();
+
+        // raw q of the wave's head(s), the (cos,sin) slices and the position itself are fetched one
+        // position ahead of the arithmetic; the head-norm weight once
+        float4 qnext[HPW], qg = make_float4(0.f, 0.f, 0.f, 0.f), ca_n = qg, cb_n = qg;
+        if (!a.prepared) {
+            if (lane < L4) qg = *reinterpret_cast<const float4*>(a.qnw + 4 * lane);
+            rope_slices<HD>(a.cs + (size_t)z0 * a.zs_cs, lane, ca_n, cb_n);
+        }
+        int pos_n = a.ctl[z0].pos;
+#pragma unroll
+        for (int hi = 0; hi < HPW; hi++) {
+            qnext[hi] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int i = wave + 4 * hi;
+            if (i < kv_mul && lane < L4)
+                qnext[hi] = *reinterpret_cast<const float4*>(a.qkv + (size_t)z0 * a.zs_qkv + (size_t)(g * kv_mul + i) * HD + 4 * lane);
+        }
+        for (int z = z0; z < z1; z++) {
+            float4 qraw[HPW];
+            const float4 ca = ca_n, cb = cb_n;
+            const int pos = pos_n;
+            const int zn = z + 1 < z1 ? z + 1 : z;               // the last round re-reads its own (unused)
+#pragma unroll
+            for (int hi = 0; hi < HPW; hi++) {
+                qraw[hi] = qnext[hi];
+                const int i = wave + 4 * hi;
+                if (i < kv_mul && lane < L4)
+                    qnext[hi] = *reinterpret_cast<const float4*>(a.qkv + (size_t)zn * a.zs_qkv + (size_t)(g * kv_mul + i) * HD + 4 * lane);
+            }
+            if (!a.prepared) rope_slices<HD>(a.cs + (size_t)zn * a.zs_cs, lane, ca_n, cb_n);
+            pos_n = a.ctl[zn].pos;
+            const int T = pos + 1;
+            const int nchunks = (T + CH - 1) / CH;
+            if (c >= nchunks) continue;                          // workgroup-uniform
+            const int Tc = (T - t0 < CH) ? T - t0 : CH;
+            const int nsteps = (Tc + 1) >> 1;
+#pragma unroll
+            for (int hi = 0; hi < HPW; hi++) {
+                const int i = wave + 4 * hi;
+                if (i >= kv_mul) continue;                       // wave-uniform
+                const int h = g * kv_mul + i;
+                // q of this head: norm + rope (k_attn's general path), slice (lane % L4) in both halves
+                float4 q4 = qraw[hi];
+                if (!a.prepared) q4 = headnorm_rope_vals<HD>(q4, qg, ca, cb, lane);
+                {
+                    const float ox = lane_xor_f<32>(q4.x), oy = lane_xor_f<32>(q4.y);
+                    const float oz = lane_xor_f<32>(q4.z), ow = lane_xor_f<32>(q4.w);
+                    if (half) q4 = make_float4(ox, oy, oz, ow);
+                }
+                // scores (k_attn): step s handles position t = 2*s + half
+                float cpart[32];
+#pragma unroll
+                for (int blk = 0; blk < 4; blk++) {
+                    if (8 * blk < nsteps) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const int step = 8 * blk + k;
+                            const int t = 2 * step + half;
+                            float cdot = 0.0f;
+                            if (act) {
+                                const float4 k4 = *reinterpret_cast<const float4*>(Ks + t * HD + 4 * l);
+                                cdot = q4.x * k4.x;
+                                cdot = cdot + q4.y * k4.y;
+                                cdot = cdot + q4.z * k4.z;
+                                cdot = cdot + q4.w * k4.w;
+                            }
+                            cpart[step] = cdot;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) cpart[8 * blk + k] = 0.0f;
+                    }
+                }
+                const float dot = transpose_sum32(cpart, l);
+                const bool valid = (2 * l + half) < Tc;
+                const float mys = valid ? dot / root : -3.0e38f;
+                const float m = wave_max(mys);
+                const float e = valid ? q3_expf(mys - m) : 0.0f;
+                const float lsum = bfly64(e);
+                // weighted sum of V
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (Tc == CH) {
+#pragma unroll
+                    for (int step = 0; step < CH / 2; step++) {
+                        if ((step & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                        const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), step));
+                        const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), 32 + step));
+                        const float et = half ? e1 : e0;
+                        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (act) v4 = *reinterpret_cast<const float4*>(Vs + (2 * step + half) * HD + 4 * l);
+                        acc.x = acc.x + et * v4.x;
+                        acc.y = acc.y + et * v4.y;
+                        acc.z = acc.z + et * v4.z;
+                        acc.w = acc.w + et * v4.w;
+                    }
+                } else
+#pragma unroll
+                for (int blk = 0; blk < 4; blk++) {
+                    if (8 * blk < nsteps) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const int step = 8 * blk + k;
+                            const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), step));
+                            const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), 32 + step));
+                            const float et = half ? e1 : e0;
+                            const int t = 2 * step + half;
+                            float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (act) v4 = *reinterpret_cast<const float4*>(Vs + t * HD + 4 * l);
+                            const bool on = t < Tc;
+                            acc.x = on ? acc.x + et * v4.x : acc.x;
+                            acc.y = on ? acc.y + et * v4.y : acc.y;
+                            acc.z = on ? acc.z + et * v4.z : acc.z;
+                            acc.w = on ? acc.w + et * v4.w : acc.w;
+                        }
+                    }
+                }
+                float4 o;
+                o.x = acc.x + lane_xor_f<32>(acc.x);
+                o.y = acc.y + lane_xor_f<32>(acc.y);
+                o.z = acc.z + lane_xor_f<32>(acc.z);
+                o.w = acc.w + lane_xor_f<32>(acc.w);
+                if (multi) {
+                    if (lane < L4) {
+                        float* pp = a.part + (size_t)z * a.zs_part + ((size_t)h * a.max_chunks + c) * (HD + 2);
+                        st_sc1_f2(pp + 4 * lane, o.x, o.y);
+                        st_sc1_f2(pp + 4 * lane + 2, o.z, o.w);
+                        if (lane == 0) st_sc1_f2(pp + HD, m, lsum);
+                    }
+                } else {
+                    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (lane < L4) {
+                        y.x = o.x / lsum;
+                        y.y = o.y / lsum;
+                        y.z = o.z / lsum;
+                        y.w = o.w / lsum;
+                    }
+                    float scale;
+                    const int packed = quantize_group16(y, scale);
+                    if (lane < L4) {
+                        reinterpret_cast<int*>(a.oq + (size_t)z * a.zs_oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
+                        if ((lane & 15) == 0) (a.os + (size_t)z * a.zs_os)[((size_t)h * HD + 4 * lane) >> 6] = scale;
+                        if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)z * a.zs_of + (size_t)h * HD + 4 * lane) = y;
+                    }
+                }
+            }
+        }
+        if (multi == ATT_MERGE) {
+            // One publication for the whole block: every storing wave drains its write-through stores,
+            // the workgroup meets, lane zi takes the ticket of position z0 + zi (one round trip for all
+            // of them); the positions whose last ticket this workgroup drew are merged right here.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < z1 - z0) {
+                const int z = z0 + tid;
+                const int nchunks = a.ctl[z].pos / CH + 1;
+                int last = 0;
+                if (c < nchunks) {
+                    unsigned* tk = a.tickets + (size_t)z * a.zs_tickets + g;
+                    const unsigned t = __hip_atomic_fetch_add((g_u32*)tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = (t == (unsigned)(nchunks - 1)) ? 1 : 0;
+                    if (last) __hip_atomic_store((g_u32*)tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                last_flags[tid] = last;
+            }
+            __syncthreads();
+            for (int z = z0; z < z1; z++) {
+                if (!last_flags[z - z0]) continue;                // workgroup-uniform
+                Attn az = a;
+                az.part += (size_t)z * a.zs_part;
+                az.oq += (size_t)z * a.zs_oq;
+                az.os += (size_t)z * a.zs_os;
+                if (a.of) az.of += (size_t)z * a.zs_of;
+                const int nchunks = a.ctl[z].pos / CH + 1;
+                for (int i = wave; i < kv_mul; i += 4) merge_partials<HD>(az, g * kv_mul + i, nchunks, lane);
+            }
+        }
+        __syncthreads();                                         // every wave is done with this tile
+    }
+}
+
 // ---- ATT_LONG: merge of the chunk partials as its own launch ---------------------------
 // One wave per 64 consecutive output values (= one quantisation group; HD/64 waves per head),
 // lane = one value.  The sums over chunks are sequential by contract (q3_numerics.h), but every
@@ -622,8 +860,25 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st) {
         exit(EXIT_FAILURE);
     }
     const int nz = a.nz > 1 ? a.nz : 1;
-    dim3 grid(a.n_kv, mode == ATT_SINGLE ? 1 : chunk_slots, nz);
     const bool two = a.n_heads / a.n_kv > 4;
+    const int slots = mode == ATT_SINGLE ? 1 : chunk_slots;
+    if (nz > 1) {
+        // a pass of the batched prompt path: blocks of positions share a staged tile; as many positions
+        // per block as still leaves ~2 workgroups per CU
+        int zb = a.n_kv * slots * nz / 512;
+        zb = zb < 1 ? 1 : (zb > 8 ? 8 : zb);
+        dim3 gridb(a.n_kv, slots, (nz + zb - 1) / zb);
+        if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn_block<128, 1>), gridb, dim3(256), 0, st, a, (int)mode, zb);
+        else if (a.hd == 128) hipLaunchKernelGGL((k_attn_block<128, 2>), gridb, dim3(256), 0, st, a, (int)mode, zb);
+        else if (!two) hipLaunchKernelGGL((k_attn_block<64, 1>), gridb, dim3(256), 0, st, a, (int)mode, zb);
+        else hipLaunchKernelGGL((k_attn_block<64, 2>), gridb, dim3(256), 0, st, a, (int)mode, zb);
+        if (mode == ATT_LONG) {
+            if (a.hd == 128) hipLaunchKernelGGL(k_attn_merge<128>, dim3(a.n_heads * 2, nz), dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(k_attn_merge<64>, dim3(a.n_heads, nz), dim3(64), 0, st, a);
+        }
+        return;
+    }
+    dim3 grid(a.n_kv, slots, nz);
     if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn<128, 1>), grid, dim3(256), 0, st, a, (int)mode);
     else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, (int)mode);
     else if (!two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, (int)mode);

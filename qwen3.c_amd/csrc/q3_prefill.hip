@@ -254,7 +254,7 @@ template <int EPI, int RT>
 __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ W, const float* __restrict__ S, int n,
                                                      int d, const int8_t* __restrict__ xq,
                                                      const float* __restrict__ xs, int ntok,
-                                                     float* __restrict__ out, int ldo) {
+                                                     float* __restrict__ out, int ldo, int ntiles) {
     constexpr int R = 16 * RT;
     constexpr int A_BYTES = R * 512, B_BYTES = 64 * 512, WS_BYTES = 8 * R * 4, XS_BYTES = 8 * 64 * 4;
     constexpr int OFF_B = A_BYTES, OFF_WS = A_BYTES + B_BYTES, OFF_XS = OFF_WS + WS_BYTES;
@@ -263,9 +263,13 @@ __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r0 = (int)blockIdx.x * R;
     const int ng = n >> 6, nslab = n >> 9;
     const int ntok16 = (ntok + 15) & ~15;
+    // Persistent: this workgroup takes the row tiles blockIdx.x, blockIdx.x + gridDim.x, ..; the slabs of
+    // all of them form ONE stream (stage q = slab q % nslab of the workgroup's tile q / nslab), so the
+    // fetch waves are already deep in the next tile while the last slab of this one is multiplied.
+    const int mytiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nq = mytiles * nslab;
 
     if (wave >= 4) {
         // ---------------------------------------------------------------- FETCH
@@ -276,19 +280,22 @@ __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ 
         const __amdgpu_buffer_rsrc_t rXS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xs), 0, ntok * ng * 4, 0x00020000);
         const int t = tid - 256;
         const int prow = t >> 5, piece = t & 31;                 // this thread's (row, piece) of a slab; +8 rows per further load
-        const int va = (r0 + prow) * n + piece * 16;
+        const int va = prow * n + piece * 16;
         const int vb = prow * n + piece * 16;
-        const int vws = ((r0 + (t >> 3)) * ng + (t & 7)) * 4;    // threads < 8*R
+        const int vws = ((t >> 3) * ng + (t & 7)) * 4;           // threads < 8*R
         const int vxs = ((t >> 3) * ng + (t & 7)) * 4;
-        auto fetch = [&](GemmSlab<RT>& r, int sl) {              // slab sl (wave-uniform)
+        int f_tile = (int)blockIdx.x, f_sl = 0;                  // the (tile, slab) the next fetch takes
+        auto fetch = [&](GemmSlab<RT>& r) {
+            const int sl = f_sl, r0 = f_tile * R;                // wave-uniform
+            if (++f_sl == nslab) { f_sl = 0; f_tile += (int)gridDim.x; }
 #pragma unroll
-            for (int k = 0; k < 2 * RT; k++) r.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rW, va + k * 8 * n, sl * 512, 0);
+            for (int k = 0; k < 2 * RT; k++) r.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rW, va + k * 8 * n, r0 * n + sl * 512, 0);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 if (prow + 8 * k < ntok16)                        // wave-uniform: a wave covers two rows, ntok16 is a multiple of 16
                     r.b[k] = __builtin_amdgcn_raw_buffer_load_b128(rX, vb + k * 8 * n, sl * 512, 0);
             }
-            if (t < 8 * R) r.ws = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vws, sl * 32, 0));
+            if (t < 8 * R) r.ws = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vws, r0 * ng * 4 + sl * 32, 0));
 #pragma unroll
             for (int k = 0; k < 2; k++)
                 r.xs[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rXS, vxs + k * 32 * ng * 4, sl * 32, 0));
@@ -306,20 +313,20 @@ __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ 
             for (int k = 0; k < 2; k++) reinterpret_cast<float*>(base + OFF_XS)[(t & 7) * 64 + (t >> 3) + 32 * k] = r.xs[k];
         };
         GemmSlab<RT> S0, S1, S2;                                 // three slabs in flight
-        fetch(S0, 0);
-        if (nslab > 1) fetch(S1, 1);
-        if (nslab > 2) fetch(S2, 2);
-        for (int sl = 0; sl < nslab; sl += 3) {
-            park(S0, sl & 1);
-            if (sl + 3 < nslab) fetch(S0, sl + 3);
+        fetch(S0);
+        if (nq > 1) fetch(S1);
+        if (nq > 2) fetch(S2);
+        for (int q = 0; q < nq; q += 3) {
+            park(S0, q & 1);
+            if (q + 3 < nq) fetch(S0);
             __syncthreads();
-            if (sl + 1 >= nslab) break;
-            park(S1, (sl + 1) & 1);
-            if (sl + 4 < nslab) fetch(S1, sl + 4);
+            if (q + 1 >= nq) break;
+            park(S1, (q + 1) & 1);
+            if (q + 4 < nq) fetch(S1);
             __syncthreads();
-            if (sl + 2 >= nslab) break;
-            park(S2, sl & 1);
-            if (sl + 5 < nslab) fetch(S2, sl + 5);
+            if (q + 2 >= nq) break;
+            park(S2, q & 1);
+            if (q + 5 < nq) fetch(S2);
             __syncthreads();
         }
         return;
@@ -338,9 +345,9 @@ __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 4; i++) col[r][c][i] = 0.0f;
 
-    auto compute = [&](auto par) {                           // slab in LDS buffer PAR (= slab index & 1): columns 8*PAR ..
+    auto compute = [&](int buf, auto par) {                  // slab in LDS buffer `buf`; PAR = slab index & 1: columns 8*PAR ..
         constexpr int PAR = decltype(par)::value;
-        const unsigned char* base = smem + PAR * STAGE;
+        const unsigned char* base = smem + buf * STAGE;
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             const v4i b = *reinterpret_cast<const v4i*>(base + OFF_B + slab_off(brow, 4 * g + kb));
@@ -360,52 +367,79 @@ __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ 
             }
         }
     };
-    for (int sl = 0; sl < nslab; sl += 2) {
-        __syncthreads();                                     // slab sl is in buffer 0
-        if (live) compute(std::integral_constant<int, 0>());
-        if (sl + 1 >= nslab) break;
-        __syncthreads();                                     // slab sl+1 is in buffer 1
-        if (live) compute(std::integral_constant<int, 1>());
-    }
-
     const int tokj = tt * 16 + li;
-    if (tokj >= ntok) return;
-#pragma unroll
-    for (int r = 0; r < RT; r++) {
-        float res[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float t8[8], t4[4], t2[2];
-#pragma unroll
-            for (int c = 0; c < 8; c++) t8[c] = col[r][c][i] + col[r][c + 8][i];
-#pragma unroll
-            for (int c = 0; c < 4; c++) t4[c] = t8[c] + t8[c + 4];
-#pragma unroll
-            for (int c = 0; c < 2; c++) t2[c] = t4[c] + t4[c + 2];
-            res[i] = t2[0] + t2[1];
+    int q = 0;                                               // stage counter: stage q lives in LDS buffer q & 1
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+        for (int sl = 0; sl < nslab; sl += 2) {
+            __syncthreads();                                 // stage q is in LDS
+            if (live) compute(q & 1, std::integral_constant<int, 0>());
+            q++;
+            if (sl + 1 >= nslab) break;
+            __syncthreads();
+            if (live) compute(q & 1, std::integral_constant<int, 1>());
+            q++;
         }
-        const int row = r0 + r * 16 + 4 * kb;
-        if (EPI == EPI_SWIGLU) {
-            float* o = out + (size_t)tokj * ldo + (row >> 1);
-            if (row < d) o[0] = swiglu_pair(res[0], res[1]);
-            if (row + 2 < d) o[1] = swiglu_pair(res[2], res[3]);
-        } else {
-            float* o = out + (size_t)tokj * ldo + row;
+        if (tokj < ntok) {
+            const int r0 = tile * R;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (row + i < d) o[i] = (EPI == EPI_RESID) ? o[i] + res[i] : res[i];
+            for (int r = 0; r < RT; r++) {
+                float res[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float t8[8], t4[4], t2[2];
+#pragma unroll
+                    for (int c = 0; c < 8; c++) t8[c] = col[r][c][i] + col[r][c + 8][i];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) t4[c] = t8[c] + t8[c + 4];
+#pragma unroll
+                    for (int c = 0; c < 2; c++) t2[c] = t4[c] + t4[c + 2];
+                    res[i] = t2[0] + t2[1];
+                }
+                const int row = r0 + r * 16 + 4 * kb;
+                if (EPI == EPI_SWIGLU) {
+                    float* o = out + (size_t)tokj * ldo + (row >> 1);
+                    if (row < d) o[0] = swiglu_pair(res[0], res[1]);
+                    if (row + 2 < d) o[1] = swiglu_pair(res[2], res[3]);
+                } else {
+                    float* o = out + (size_t)tokj * ldo + row;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (row + i < d) o[i] = (EPI == EPI_RESID) ? o[i] + res[i] : res[i];
+                    }
+                }
             }
         }
+#pragma unroll
+        for (int r = 0; r < RT; r++)
+#pragma unroll
+            for (int c = 0; c < 16; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) col[r][c][i] = 0.0f;
     }
+}
+
+static int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+            fprintf(stderr, "[q3hip] gemm_q8: no device properties\n");
+            exit(EXIT_FAILURE);
+        }
+        n = p.multiProcessorCount;
+    }
+    return n;
 }
 
 template <int RT>
 static void launch_gemm_lds(const int8_t* W, const float* S, int n, int d, const int8_t* xq, const float* xs, int ntok,
                             float* out, int ldo, Epi epi, hipStream_t st) {
-    const dim3 grid((d + 16 * RT - 1) / (16 * RT)), block(512);
-    if (epi == EPI_STORE) hipLaunchKernelGGL((k_gemm_q8_lds<EPI_STORE, RT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
-    else if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_q8_lds<EPI_RESID, RT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
-    else hipLaunchKernelGGL((k_gemm_q8_lds<EPI_SWIGLU, RT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo);
+    const int ntiles = (d + 16 * RT - 1) / (16 * RT);
+    const dim3 grid(ntiles < cu_count() ? ntiles : cu_count()), block(512);      // one workgroup per CU (LDS), persistent
+    if (epi == EPI_STORE) hipLaunchKernelGGL((k_gemm_q8_lds<EPI_STORE, RT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo, ntiles);
+    else if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_q8_lds<EPI_RESID, RT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo, ntiles);
+    else hipLaunchKernelGGL((k_gemm_q8_lds<EPI_SWIGLU, RT>), grid, block, 0, st, W, S, n, d, xq, xs, ntok, out, ldo, ntiles);
 }
 
 template <bool AL4>
