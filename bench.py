@@ -322,9 +322,10 @@ def main():
             drop.sampler_free(smp)
             hip.q3_device_detach(md)
             drop.model_free(md)
-    if ngpu == 1 and pos + 600 < seq and args.dtype == "q8":
-        # prompt ingestion (q3_prefill: 16 positions per pass, Q8_0 products on int8 MFMA; bit-identical
-        # to feeding the prompt through forward()) -- reported next to the decode rate, not part of `value`
+    if ngpu == 1 and pos + 600 < seq:
+        # prompt ingestion (q3_prefill: up to 64 positions per pass; Q8_0 products on int8 MFMA, bit-identical
+        # to feeding the prompt through forward(); binary16 products on f16 MFMA for --dtype fp16) --
+        # reported next to the decode rate, not part of `value`
         n_pf = 256
         prompt = (C.c_int * n_pf)(*[int(t) for t in np.random.default_rng(5).integers(0, vocab, size=n_pf)])
         hip.q3_prefill(m, prompt, 32, pos)

@@ -297,4 +297,11 @@ __device__ __forceinline__ float transpose_sum32(float (&c)[32], int l) {
     return c[0];
 }
 
+// LDS slab of the batched GEMMs (q3_prefill.hip, q3_fp16.hip): rows of 512 bytes = 32 pieces of 16 bytes;
+// the low four bits of the piece index are XORed with the row, so the 16 rows (or tokens) of an MFMA
+// k-block land in 16 different bank groups.  Byte offset of (row, piece).
+__device__ __forceinline__ int slab_off(int row, int piece) {
+    return row * 512 + ((((piece ^ row) & 15) | (piece & 16)) << 4);
+}
+
 }  // namespace q3k

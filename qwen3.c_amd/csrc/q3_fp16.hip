@@ -200,6 +200,145 @@ __global__ __launch_bounds__(256) void k_gemm_f16(const __half* __restrict__ W, 
         }
     }
 }
+// ---- the same product with both operands staged through LDS (the structure of k_gemm_q8_lds) ----
+// A workgroup owns 16*RT rows x 64 tokens and walks K in slabs of 256 halves (512 bytes per row):
+// waves 4..7 fetch (whole 128-byte lines, three slabs ahead in three register sets, parked in one of
+// two swizzled LDS buffers), waves 0..3 multiply (wave t = token tile t, all RT row tiles: per k-step
+// one activation read, RT weight reads, RT MFMAs accumulating in fp32 in the matrix core).  There is
+// no reduction-order contract to keep here, so a 16 x 16 tile costs 4 accumulator registers and the
+// row tile can be wide.  Persistent: the slabs of a workgroup's row tiles form one stream.
+template <int RT> struct HalfSlab {
+    v4i a[2 * RT];
+    v4i b[8];
+};
+
+template <int EPI, int RT>
+__global__ __launch_bounds__(512) void k_gemm_f16_lds(const __half* __restrict__ W, int n, int d, const __half* __restrict__ X,
+                                                      int ntok, float* __restrict__ out, int ldo, int ntiles) {
+    constexpr int R = 16 * RT;
+    constexpr int A_BYTES = R * 512, B_BYTES = 64 * 512;
+    constexpr int OFF_B = A_BYTES, STAGE = A_BYTES + B_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nslab = n >> 8;                                  // 256 halves per slab
+    const int ntok16 = (ntok + 15) & ~15;
+    const int mytiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nq = mytiles * nslab;
+    const int rowb = n * 2;                                    // bytes per row
+
+    if (wave >= 4) {
+        // ---------------------------------------------------------------- FETCH
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(W), 0, d * rowb, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(X), 0, ntok * rowb, 0x00020000);
+        const int t = tid - 256;
+        const int prow = t >> 5, piece = t & 31;
+        const int va = prow * rowb + piece * 16;
+        int f_tile = (int)blockIdx.x, f_sl = 0;
+        auto fetch = [&](HalfSlab<RT>& r) {
+            const int sl = f_sl, r0 = f_tile * R;
+            if (++f_sl == nslab) { f_sl = 0; f_tile += (int)gridDim.x; }
+#pragma unroll
+            for (int k = 0; k < 2 * RT; k++) r.a[k] = __builtin_amdgcn_raw_buffer_load_b128(rW, va + k * 8 * rowb, r0 * rowb + sl * 512, 0);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (prow + 8 * k < ntok16) r.b[k] = __builtin_amdgcn_raw_buffer_load_b128(rX, va + k * 8 * rowb, sl * 512, 0);
+            }
+        };
+        auto park = [&](const HalfSlab<RT>& r, int buf) {
+            unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+            for (int k = 0; k < 2 * RT; k++) *reinterpret_cast<v4i*>(base + slab_off(prow + 8 * k, piece)) = r.a[k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (prow + 8 * k < ntok16) *reinterpret_cast<v4i*>(base + OFF_B + slab_off(prow + 8 * k, piece)) = r.b[k];
+            }
+        };
+        HalfSlab<RT> S0, S1, S2;
+        fetch(S0);
+        if (nq > 1) fetch(S1);
+        if (nq > 2) fetch(S2);
+        for (int q = 0; q < nq; q += 3) {
+            park(S0, q & 1);
+            if (q + 3 < nq) fetch(S0);
+            __syncthreads();
+            if (q + 1 >= nq) break;
+            park(S1, (q + 1) & 1);
+            if (q + 4 < nq) fetch(S1);
+            __syncthreads();
+            if (q + 2 >= nq) break;
+            park(S2, q & 1);
+            if (q + 5 < nq) fetch(S2);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- MULTIPLY
+    const int tt = wave;
+    const int li = lane & 15, kb = lane >> 4;
+    const int brow = tt * 16 + li;
+    const bool live = tt * 16 < ntok;
+    const int tokj = tt * 16 + li;
+    f4 acc[RT];
+    int q = 0;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+#pragma unroll
+        for (int r = 0; r < RT; r++) acc[r] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < nslab; sl++, q++) {
+            __syncthreads();                                   // stage q is in LDS buffer q & 1
+            if (!live) continue;
+            const unsigned char* base = smem + (q & 1) * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {                   // 32 halves = 64 bytes = pieces 4*ks .. 4*ks+3
+                const v4i b = *reinterpret_cast<const v4i*>(base + OFF_B + slab_off(brow, 4 * ks + kb));
+#pragma unroll
+                for (int r = 0; r < RT; r++) {
+                    const v4i a = *reinterpret_cast<const v4i*>(base + slab_off(r * 16 + li, 4 * ks + kb));
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), acc[r], 0, 0, 0);
+                }
+            }
+        }
+        if (tokj < ntok) {
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                const int row = tile * R + r * 16 + 4 * kb;
+                if (EPI == EPI_SWIGLU) {
+                    float* o = out + (size_t)tokj * ldo + (row >> 1);
+                    if (row < d) o[0] = swiglu_pair(acc[r][0], acc[r][1]);
+                    if (row + 2 < d) o[1] = swiglu_pair(acc[r][2], acc[r][3]);
+                } else {
+                    float* o = out + (size_t)tokj * ldo + row;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (row + i < d) o[i] = (EPI == EPI_RESID) ? o[i] + acc[r][i] : acc[r][i];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int RT>
+static void launch_gemm_f16_lds(const __half* w, int n, int d, const __half* x, int ntok, float* out, int ldo, Epi epi, hipStream_t st) {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+            fprintf(stderr, "[q3hip] gemm_f16: no device properties\n");
+            exit(EXIT_FAILURE);
+        }
+        ncu = p.multiProcessorCount;
+    }
+    const int ntiles = (d + 16 * RT - 1) / (16 * RT);
+    const dim3 grid(ntiles < ncu ? ntiles : ncu), block(512);
+    if (epi == EPI_STORE) hipLaunchKernelGGL((k_gemm_f16_lds<EPI_STORE, RT>), grid, block, 0, st, w, n, d, x, ntok, out, ldo, ntiles);
+    else if (epi == EPI_RESID) hipLaunchKernelGGL((k_gemm_f16_lds<EPI_RESID, RT>), grid, block, 0, st, w, n, d, x, ntok, out, ldo, ntiles);
+    else hipLaunchKernelGGL((k_gemm_f16_lds<EPI_SWIGLU, RT>), grid, block, 0, st, w, n, d, x, ntok, out, ldo, ntiles);
+}
+
 void gemm_f16(const void* W, int n, int d, const void* X, int ntok, float* out, int ldo, Epi epi, hipStream_t st) {
     if (n % 32 || d % 2 || ntok < 1 || ntok > 64 || (long long)d * n * 2 >= (1ll << 31)) {
         fprintf(stderr, "[q3hip] gemm_f16: bad shape (n=%d d=%d tokens=%d)\n", n, d, ntok);
@@ -207,6 +346,12 @@ void gemm_f16(const void* W, int n, int d, const void* X, int ntok, float* out, 
     }
     const __half* w = reinterpret_cast<const __half*>(W);
     const __half* x = reinterpret_cast<const __half*>(X);
+    if (n % 256 == 0) {
+        if (d >= 16384) launch_gemm_f16_lds<4>(w, n, d, x, ntok, out, ldo, epi, st);
+        else if (d >= 6144) launch_gemm_f16_lds<2>(w, n, d, x, ntok, out, ldo, epi, st);
+        else launch_gemm_f16_lds<1>(w, n, d, x, ntok, out, ldo, epi, st);
+        return;
+    }
     const dim3 grid((d + 15) / 16), block(64 * ((ntok + 15) / 16));
     if (epi == EPI_STORE) hipLaunchKernelGGL(k_gemm_f16<EPI_STORE>, grid, block, 0, st, w, n, d, x, ntok, out, ldo);
     else if (epi == EPI_RESID) hipLaunchKernelGGL(k_gemm_f16<EPI_RESID>, grid, block, 0, st, w, n, d, x, ntok, out, ldo);

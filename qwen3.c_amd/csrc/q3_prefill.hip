@@ -246,10 +246,6 @@ template <int RT> struct GemmSlab {       // what one fetching thread holds of a
     float xs[2];
 };
 
-__device__ __forceinline__ int slab_off(int row, int piece) {       // byte offset of (row, 16-byte piece) in an LDS slab
-    return row * 512 + ((((piece ^ row) & 15) | (piece & 16)) << 4);
-}
-
 template <int EPI, int RT>
 __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ W, const float* __restrict__ S, int n,
                                                      int d, const int8_t* __restrict__ xq,
