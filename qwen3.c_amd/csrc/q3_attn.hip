@@ -72,11 +72,11 @@ template <int HD>
 __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks, int lane) {
     constexpr int L4 = HD / 4;
     constexpr int ST = HD + 2;
-    constexpr int AH = 8;                 // O_c rows requested ahead of the accumulation
+    constexpr int AH = 16;                // O_c rows per burst = every chunk the in-launch merge ever sees (Q3_ATT_LONG / 64)
     const float* base = a.part + (size_t)h * a.max_chunks * ST;
-    // Everything the first 64 chunks need is requested in ONE burst -- their (m_c, l_c) pairs,
-    // one per lane, and the first AH rows O_c -- so the usual context (<= 4096 positions)
-    // costs a single memory round trip before the arithmetic starts.
+    // Everything is requested in ONE burst -- the (m_c, l_c) pairs, one per lane, and the rows O_c --
+    // so the merge costs a single memory round trip before the arithmetic starts.  (Contexts beyond
+    // 16 chunks take further bursts; the launch shapes in use never get there: ATT_LONG has its own kernel.)
     float2 ml0 = make_float2(-3.0e38f, 0.0f);
     if (lane < nchunks) ml0 = ld_sc1_f2(base + (size_t)lane * ST + HD);
     float4 o[AH];
@@ -101,10 +101,10 @@ __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks
         }
         const int cnt = (nchunks - c0 < 64) ? nchunks - c0 : 64;
         for (int k0 = 0; k0 < cnt; k0 += AH) {
-            float4 nx[AH];                 // the next AH rows, requested before this group is consumed
-            const int nb = c0 + k0 + AH;
+            if (c0 + k0 > 0) {             // a further burst (long contexts only)
 #pragma unroll
-            for (int k = 0; k < AH; k++) nx[k] = (nb < nchunks) ? ld_partial_row<HD>(base, nb + k < nchunks ? nb + k : nchunks - 1, lane) : o[k];
+                for (int k = 0; k < AH; k++) o[k] = ld_partial_row<HD>(base, c0 + k0 + k < nchunks ? c0 + k0 + k : nchunks - 1, lane);
+            }
 #pragma unroll
             for (int k = 0; k < AH; k++) {
                 if (k0 + k < cnt) {
@@ -117,8 +117,6 @@ __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks
                     A.w = A.w + w * o[k].w;
                 }
             }
-#pragma unroll
-            for (int k = 0; k < AH; k++) o[k] = nx[k];
         }
     }
     float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -868,6 +866,10 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st) {
         int zb = a.n_kv * slots * nz / 512;
         zb = zb < 1 ? 1 : (zb > 8 ? 8 : zb);
         dim3 gridb(a.n_kv, slots, (nz + zb - 1) / zb);
+        // Beyond a few chunks a pass merges in the wide second launch (one wave per 64 outputs, all
+        // positions at once): in-launch, the workgroup of the last chunk would merge every position of
+        // its block, one after the other, while the rest of the chip is done.  Same sums, same order.
+        if (mode == ATT_MERGE && slots > 4) mode = ATT_LONG;
         if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn_block<128, 1>), gridb, dim3(256), 0, st, a, (int)mode, zb);
         else if (a.hd == 128) hipLaunchKernelGGL((k_attn_block<128, 2>), gridb, dim3(256), 0, st, a, (int)mode, zb);
         else if (!two) hipLaunchKernelGGL((k_attn_block<64, 1>), gridb, dim3(256), 0, st, a, (int)mode, zb);
