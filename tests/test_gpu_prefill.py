@@ -33,12 +33,21 @@ def test_mfma_gemm_equals_gemv_per_token(hip, orc, n, d, ntok):
         assert np.array_equal(out[t], tree), (t,)
 
 
-@pytest.mark.parametrize("name,n", [("tiny", 37), ("small", 50), ("4Bmini", 70)])
-def test_prefill_equals_token_by_token(hip, name, n):
+@pytest.mark.parametrize("name,n,over", [
+    ("tiny", 37, {}), ("small", 50, {}), ("4Bmini", 70, {}),
+    # several chunks per position: blocks of positions on one staged K/V tile, in-launch merge (<= 4 chunk slots)
+    ("small", 230, {}),
+    # more than four chunk slots: the pass merges in the wide second launch
+    ("small", 420, {}),
+    # eight query heads per kv head (two heads per wave), head_dim 128 and 64
+    ("small", 150, {"n_heads": 8}), ("tiny", 200, {"n_heads": 8, "seq_len": 256}),
+])
+def test_prefill_equals_token_by_token(hip, name, n, over):
     """logits after the prompt, and every later decode step (i.e. the KV cache the prompt left), are
-    bit-identical whether the prompt went in 16 positions at a time or one forward() per token"""
-    path = os.path.join(Q.tmp_dir(), f"{name}.bin")
-    spec = Q.synth(name, path)
+    bit-identical whether the prompt went in 64 positions at a time or one forward() per token"""
+    tag = "".join(f"_{k}{v}" for k, v in sorted(over.items()))
+    path = os.path.join(Q.tmp_dir(), f"{name}{tag}.bin")
+    spec = Q.synth(name, path, **over)
     ma = hip.q3_model_open(path.encode(), 0, 0)
     mb = hip.q3_model_open(path.encode(), 0, 0)
     rng = np.random.default_rng(n)
