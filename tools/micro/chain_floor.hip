@@ -1,0 +1,101 @@
+// What does the PLATFORM charge for the decode step's dependency structure, with the arithmetic taken out?
+// A hipGraph of 182 dependent launches per token (36 layers x {qkv, attention, wo, gate/up, down} + begin +
+// classifier) in which every launch only streams the bytes its stage reads (nt 16-byte loads, 1024 threads per
+// workgroup, 256 workgroups, a rolling window of loads per thread) and then writes one small vector the next
+// launch reads first (so the launches are truly dependent, as the residual makes them).  No norm, no quantise, no dot
+// products, no reductions.  Qwen3-4B byte counts.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/micro/chain_floor.hip -o tools/micro/chain_floor.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// dep_in: 2560 floats the previous launch wrote (read first, like the residual); dep_out: what this one writes
+template <int DEPTH>
+__global__ __launch_bounds__(1024) void k_stage(const v4i* __restrict__ w, size_t nvec, const float* dep_in, float* dep_out) {
+    const int tid = threadIdx.x;
+    // the dependent read every stage starts with
+    float d = dep_in[(blockIdx.x * 7 + tid) % 2560];
+    const size_t per = (nvec + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per;
+    const size_t hi = lo + per < nvec ? lo + per : nvec;
+    v4i acc = {0, 0, 0, 0};
+    for (size_t i = lo + tid; i < hi; i += (size_t)1024 * DEPTH) {
+        v4i v[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) {
+            const size_t j = i + (size_t)k * 1024;
+            v[k] = j < hi ? __builtin_nontemporal_load(&w[j]) : acc;
+        }
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) acc ^= v[k];
+    }
+    const int r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (tid < 10) dep_out[(blockIdx.x * 10 + tid) % 2560] = d + (float)(r & 1);
+}
+
+int main(int argc, char** argv) {
+    const int L = 36;
+    // bytes each stage reads (Qwen3-4B, Q8_0 codes + scales); attention at short context reads ~0.2 MB
+    const size_t B_QKV = 16711680 + 0, B_ATT = 200000, B_WO = 11141120, B_GU = 52920320, B_DN = 26460160, B_CLS = 413265920;
+    const size_t per_layer = B_QKV + B_ATT + B_WO + B_GU + B_DN;
+    const size_t total = per_layer * L + B_CLS;
+    char* buf; float *dA, *dB;
+    CHK(hipMalloc(&buf, total + 4096)); CHK(hipMemset(buf, 1, total));
+    CHK(hipMalloc(&dA, 2560 * 4)); CHK(hipMalloc(&dB, 2560 * 4));
+    CHK(hipMemset(dA, 0, 2560 * 4)); CHK(hipMemset(dB, 0, 2560 * 4));
+    hipStream_t st; CHK(hipStreamCreate(&st));
+    for (int variant = 0; variant < 2; variant++) {
+        const int grid = 256;
+        hipGraph_t g; hipGraphExec_t ge;
+        CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        size_t off = 0; int n = 0;
+        auto stage = [&](size_t bytes) {
+            const float* in = (n & 1) ? dB : dA; float* out = (n & 1) ? dA : dB;
+            if (variant == 0) hipLaunchKernelGGL(k_stage<4>, dim3(grid), dim3(1024), 0, st, (const v4i*)(buf + off), bytes / 16, in, out);
+            else hipLaunchKernelGGL(k_stage<8>, dim3(grid), dim3(1024), 0, st, (const v4i*)(buf + off), bytes / 16, in, out);
+            off += bytes & ~(size_t)15; n++;
+        };
+        stage(10240);                                   // begin
+        for (int l = 0; l < L; l++) { stage(B_QKV); stage(B_ATT); stage(B_WO); stage(B_GU); stage(B_DN); }
+        stage(B_CLS);
+        CHK(hipStreamEndCapture(st, &g));
+        CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int i = 0; i < 5; i++) CHK(hipGraphLaunch(ge, st));
+        CHK(hipStreamSynchronize(st));
+        hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        const int reps = 50;
+        CHK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; i++) CHK(hipGraphLaunch(ge, st));
+        CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps;
+        printf("variant %d (%d loads in flight per thread): %d launches, %.1f us per token-equivalent = %.1f tok/s, %.2f TB/s = %.1f %% of 8 TB/s; per layer %.2f us\n",
+               variant, variant ? 8 : 4, n, us, 1e6 / us, total / us / 1e6, total / us / 1e6 / 8 * 100, (us - (double)B_CLS / 6.2e6) / L);
+        // per-stage: the same launches one at a time, eagerly timed over 200 launches each
+        if (variant == 1) {
+            const size_t sizes[5] = {B_QKV, B_ATT, B_WO, B_GU, B_DN}; const char* names[5] = {"qkv", "attn-sized", "wo", "gate/up", "down"};
+            for (int s = 0; s < 5; s++) {
+                hipGraph_t g2; hipGraphExec_t ge2;
+                CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+                size_t o2 = 0;
+                for (int i = 0; i < 36; i++) {
+                    hipLaunchKernelGGL(k_stage<8>, dim3(grid), dim3(1024), 0, st, (const v4i*)(buf + o2), sizes[s] / 16, (i & 1) ? dB : dA, (i & 1) ? dA : dB);
+                    o2 += per_layer & ~(size_t)15;
+                }
+                CHK(hipStreamEndCapture(st, &g2));
+                CHK(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
+                CHK(hipGraphLaunch(ge2, st)); CHK(hipStreamSynchronize(st));
+                CHK(hipEventRecord(e0, st));
+                for (int i = 0; i < 20; i++) CHK(hipGraphLaunch(ge2, st));
+                CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
+                CHK(hipEventElapsedTime(&ms, e0, e1));
+                const double u = ms * 1e3 / (20 * 36);
+                printf("  %-10s %9zu B: %.2f us per dependent launch in a graph = %.2f TB/s\n", names[s], sizes[s], u, sizes[s] / u / 1e6);
+            }
+        }
+    }
+    return 0;
+}
