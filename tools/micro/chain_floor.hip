@@ -13,8 +13,8 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 // dep_in: 2560 floats the previous launch wrote (read first, like the residual); dep_out: what this one writes
-template <int DEPTH>
-__global__ __launch_bounds__(1024) void k_stage(const v4i* __restrict__ w, size_t nvec, const float* dep_in, float* dep_out) {
+template <int DEPTH, int NT>
+__global__ __launch_bounds__(NT) void k_stage(const v4i* __restrict__ w, size_t nvec, const float* dep_in, float* dep_out) {
     const int tid = threadIdx.x;
     // the dependent read every stage starts with
     float d = dep_in[(blockIdx.x * 7 + tid) % 2560];
@@ -22,11 +22,11 @@ __global__ __launch_bounds__(1024) void k_stage(const v4i* __restrict__ w, size_
     const size_t lo = (size_t)blockIdx.x * per;
     const size_t hi = lo + per < nvec ? lo + per : nvec;
     v4i acc = {0, 0, 0, 0};
-    for (size_t i = lo + tid; i < hi; i += (size_t)1024 * DEPTH) {
+    for (size_t i = lo + tid; i < hi; i += (size_t)NT * DEPTH) {
         v4i v[DEPTH];
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) {
-            const size_t j = i + (size_t)k * 1024;
+            const size_t j = i + (size_t)k * NT;
             v[k] = j < hi ? __builtin_nontemporal_load(&w[j]) : acc;
         }
 #pragma unroll
@@ -47,15 +47,24 @@ int main(int argc, char** argv) {
     CHK(hipMalloc(&dA, 2560 * 4)); CHK(hipMalloc(&dB, 2560 * 4));
     CHK(hipMemset(dA, 0, 2560 * 4)); CHK(hipMemset(dB, 0, 2560 * 4));
     hipStream_t st; CHK(hipStreamCreate(&st));
-    for (int variant = 0; variant < 2; variant++) {
-        const int grid = 256;
+    struct V { int depth, nt, grid; };
+    const V vs[] = {{4, 1024, 256}, {8, 1024, 256}, {8, 512, 512}, {8, 256, 1024}, {16, 512, 256}, {4, 1024, 512}};
+    for (int variant = 0; variant < (int)(sizeof(vs) / sizeof(vs[0])); variant++) {
+        const int grid = vs[variant].grid;
         hipGraph_t g; hipGraphExec_t ge;
         CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
         size_t off = 0; int n = 0;
         auto stage = [&](size_t bytes) {
             const float* in = (n & 1) ? dB : dA; float* out = (n & 1) ? dA : dB;
-            if (variant == 0) hipLaunchKernelGGL(k_stage<4>, dim3(grid), dim3(1024), 0, st, (const v4i*)(buf + off), bytes / 16, in, out);
-            else hipLaunchKernelGGL(k_stage<8>, dim3(grid), dim3(1024), 0, st, (const v4i*)(buf + off), bytes / 16, in, out);
+            const v4i* w = (const v4i*)(buf + off);
+            switch (variant) {
+                case 0: hipLaunchKernelGGL((k_stage<4, 1024>), dim3(grid), dim3(1024), 0, st, w, bytes / 16, in, out); break;
+                case 1: hipLaunchKernelGGL((k_stage<8, 1024>), dim3(grid), dim3(1024), 0, st, w, bytes / 16, in, out); break;
+                case 2: hipLaunchKernelGGL((k_stage<8, 512>), dim3(grid), dim3(512), 0, st, w, bytes / 16, in, out); break;
+                case 3: hipLaunchKernelGGL((k_stage<8, 256>), dim3(grid), dim3(256), 0, st, w, bytes / 16, in, out); break;
+                case 4: hipLaunchKernelGGL((k_stage<16, 512>), dim3(grid), dim3(512), 0, st, w, bytes / 16, in, out); break;
+                default: hipLaunchKernelGGL((k_stage<4, 1024>), dim3(grid), dim3(1024), 0, st, w, bytes / 16, in, out); break;
+            }
             off += bytes & ~(size_t)15; n++;
         };
         stage(10240);                                   // begin
@@ -72,8 +81,8 @@ int main(int argc, char** argv) {
         CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
         float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps;
-        printf("variant %d (%d loads in flight per thread): %d launches, %.1f us per token-equivalent = %.1f tok/s, %.2f TB/s = %.1f %% of 8 TB/s; per layer %.2f us\n",
-               variant, variant ? 8 : 4, n, us, 1e6 / us, total / us / 1e6, total / us / 1e6 / 8 * 100, (us - (double)B_CLS / 6.2e6) / L);
+        printf("%d workgroups x %d threads, %d loads in flight per thread: %d launches, %.1f us per token-equivalent = %.1f tok/s, %.2f TB/s = %.1f %% of 8 TB/s; per layer %.2f us\n",
+               grid, vs[variant].nt, vs[variant].depth, n, us, 1e6 / us, total / us / 1e6, total / us / 1e6 / 8 * 100, (us - (double)B_CLS / 6.2e6) / L);
         // per-stage: the same launches one at a time, eagerly timed over 200 launches each
         if (variant == 1) {
             const size_t sizes[5] = {B_QKV, B_ATT, B_WO, B_GU, B_DN}; const char* names[5] = {"qkv", "attn-sized", "wo", "gate/up", "down"};
@@ -82,7 +91,7 @@ int main(int argc, char** argv) {
                 CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
                 size_t o2 = 0;
                 for (int i = 0; i < 36; i++) {
-                    hipLaunchKernelGGL(k_stage<8>, dim3(grid), dim3(1024), 0, st, (const v4i*)(buf + o2), sizes[s] / 16, (i & 1) ? dB : dA, (i & 1) ? dA : dB);
+                    hipLaunchKernelGGL((k_stage<8, 1024>), dim3(grid), dim3(1024), 0, st, (const v4i*)(buf + o2), sizes[s] / 16, (i & 1) ? dB : dA, (i & 1) ? dA : dB);
                     o2 += per_layer & ~(size_t)15;
                 }
                 CHK(hipStreamEndCapture(st, &g2));
