@@ -28,6 +28,9 @@ if what == "ctx":
                   f"attn {k.get('attn', {}).get('us')} us  combine {k.get('attn_combine', {}).get('us')} us", flush=True)
 else:
     for mdl in ("0.6B", "1.7B", "4B", "8B"):
-        d = run(["--steps", "128", "--warmup", "8", "--model", mdl, "--no-cpu-baseline", "--no-roofline"])
+        d = run(["--steps", "128", "--warmup", "8", "--model", mdl, "--no-cpu-baseline", "--no-roofline", "--no-dropin"])
         if d:
-            print(f"{mdl:5s}: {d['value']:8.1f} tok/s  {d['ms_per_step']:.3f} ms  frac {d['hbm_roofline_frac_step']:.3f}", flush=True)
+            c = d.get("contexts", {})
+            ctx = "  ".join(f"ctx {k}: {v['tokens_per_s']:.0f} ({v['frac_of_hbm_roofline']:.3f})" for k, v in c.items() if k != "0")
+            print(f"{mdl:5s}: {d['value']:8.1f} tok/s  {d['ms_per_step']:.3f} ms  frac {d['hbm_roofline_frac_step']:.3f}  "
+                  f"prefill {d.get('prefill_tokens_per_s')} tok/s  {ctx}", flush=True)
