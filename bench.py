@@ -93,6 +93,68 @@ def cpu_baseline(path, vocab, budget_s=20.0):
                                                      if kind == "reference" else "")}
 
 
+def share_id(rank, world, payload, tmp, timeout_s=300.0):
+    """Rank 0 hands `payload` (the 128-byte RCCL unique id) to the other ranks of this node.  First choice: a
+    TCP exchange on MASTER_ADDR:MASTER_PORT (nothing else of this job uses that port: torch.distributed is not
+    loaded), every message tagged so that a foreign listener on the port is recognised.  Fallback when rank 0
+    cannot bind it: a file keyed by port and world size, accepted only when written after this job started."""
+    import socket
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "0"))
+    tag = b"Q3ID" + bytes([world & 255])
+    idfile = os.path.join(tmp, f"rccl_id_{port}_{world}")
+    started = time.time()
+    if rank == 0:
+        assert payload is not None and len(payload) == 128
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(tag + payload)
+        os.replace(idfile + ".tmp", idfile)
+        srv = None
+        if port:
+            try:
+                srv = socket.socket()
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                srv.listen(world)
+            except OSError:
+                srv = None
+        if srv is not None:
+            srv.settimeout(1.0)
+            served = 0
+            while served < world - 1 and time.time() - started < timeout_s:
+                try:
+                    c, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                with c:
+                    c.sendall(tag + payload)
+                served += 1
+            srv.close()
+        return payload
+    while time.time() - started < timeout_s:
+        if port:
+            try:
+                with socket.create_connection((addr, port), timeout=1.0) as c:
+                    c.settimeout(5.0)
+                    got = b""
+                    while len(got) < len(tag) + 128:
+                        part = c.recv(len(tag) + 128 - len(got))
+                        if not part:
+                            break
+                        got += part
+                if got[:len(tag)] == tag and len(got) == len(tag) + 128:
+                    return got[len(tag):]
+            except OSError:
+                pass
+        # the file: only after rank 0 has had time to bind, and only a file of THIS job
+        if time.time() - started > 15.0 and os.path.exists(idfile) and os.path.getmtime(idfile) > started - 120.0:
+            got = open(idfile, "rb").read()
+            if got[:len(tag)] == tag and len(got) == len(tag) + 128:
+                return got[len(tag):]
+        time.sleep(0.05)
+    raise SystemExit("[bench] rank 0 never published the RCCL id")
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` with no launcher: start N fresh rank processes (one per GPU) before
     anything in THIS process has touched HIP, relay rank 0's JSON line, fail if any rank fails."""
@@ -168,29 +230,17 @@ def main():
         # Rendezvous without torch: torch's wheel bundles its own HIP/RCCL runtimes, which must
         # not share a process with the ROCm 7.2 ones libq3hip.so links.  All ranks are on one
         # node, so rank 0 publishes the RCCL unique id in a file keyed by MASTER_PORT.
-        port = os.environ.get("MASTER_PORT", "0")
-        idfile = os.path.join(Q.tmp_dir(), f"rccl_id_{port}_{ngpu}")
-        started = time.time()
         if rank == 0:
             buf = (C.c_char * 128)()
             assert hip.q3_pipeline_unique_id(buf) == 0
-            with open(idfile + ".tmp", "wb") as f:
-                f.write(bytes(buf))
-            os.replace(idfile + ".tmp", idfile)
+            raw = share_id(0, ngpu, bytes(buf), Q.tmp_dir())
         else:
-            while not (os.path.exists(idfile) and os.path.getmtime(idfile) > started - 30.0
-                       and os.path.getsize(idfile) == 128):
-                if time.time() - started > 300:
-                    raise SystemExit("[bench] rank 0 never published the RCCL id")
-                time.sleep(0.05)
-        raw = open(idfile, "rb").read()
+            raw = share_id(rank, ngpu, None, Q.tmp_dir())
         if hip.q3_device_count() < ngpu:
             raise SystemExit(f"[bench] {ngpu} ranks but {hip.q3_device_count()} HIP device(s): one process per GPU")
         assert hip.q3_pipeline_init(rank, ngpu, raw) == 0
         assert hip.q3_pipeline_size() == ngpu, (hip.q3_pipeline_size(), ngpu)
         hip.q3_pipeline_allreduce_max(0.0)            # everybody has joined
-        if rank == 0:
-            os.remove(idfile)
 
     tmp = Q.tmp_dir()
     path = os.path.join(tmp, f"{args.model}.bin")
