@@ -4,8 +4,8 @@
 //
 //   k_rows_quantize   the GEMV prologue (rmsnorm + q8_quantize, or q8_quantize alone) for B
 //                     activation rows at once: a workgroup per row and 1024-element span
-//   k_gemm_q8         out[t][r] = W[r][:] . x_t for 16 rows x 16 tokens per wave with
-//                     v_mfma_i32_16x16x64_i8: K = 64 is exactly one Q8_0 group, so ONE MFMA
+//   k_gemm_q8_lds /   out[t][r] = W[r][:] . x_t with v_mfma_i32_16x16x64_i8, operands staged through LDS in
+//   k_gemm_q8         whole lines (or gathered per lane, for narrow rows): K = 64 is exactly one Q8_0 group, so ONE MFMA
 //                     yields the exact int32 group dots of 256 (row, token) pairs; each is then
 //                     scaled ((float)dot * ws) * xs and accumulated in the SUM16 tree of
 //                     q3_numerics.h -- the same operations in the same order as the decode GEMV,
@@ -92,16 +92,10 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 //   A: lane l holds A[row l&15][k = 16*(l>>4) .. +15];  B the same with token l&15
 //   D: lane l, register i holds D[row 4*(l>>4) + i][token l&15]
 //
-// Where it stands (profiles/r02_prefill_gemm_variants.json): 63 us for the gate/up GEMM of 64 tokens, for
-// 56 MB of weights (9 us of HBM time) and ~5 us of VALU issue for the fp32 scale-accumulate of 50 M group
-// dots -- neither roofline.  Variants measured this round, all bit-exact, none faster: the four waves
-// splitting the SUM16 columns instead of the tokens (round 1: 75 us); column pairs in butterfly order
-// folded into running trees, which needs 24 instead of 64 accumulator registers (80 us); three rounds of
-// weights in flight instead of one (67 us); two row tiles per workgroup (141 us) and 64 x 64 tiles with
-// sixteen waves (119 us).  The time follows the number of 64-byte row segments the CU's vector-memory
-// path has to gather per MFMA (16 rows x 64 B per operand load), not the bytes: the next step is to stage
-// whole 128-byte lines of both operands through LDS (the guide's "x through LDS in full lines" row) --
-// not built.
+// This kernel lets every lane gather its own 16-byte operand slices (32 half lines per MFMA through the CU's
+// vector-memory path) and its time follows that count: 63 us for the gate/up GEMM of 64 tokens
+// (profiles/r02_prefill_gemm_variants.json lists the register-only variants measured, none faster).  It now
+// serves the shapes k_gemm_q8_lds below does not take (rows narrower than 512 bytes: the small fixtures).
 struct GemmSub {          // four consecutive groups: this lane's k-slices and the scales it needs
     v4i a[4], b[4];
     float sw[4][4];       // [output row i][group]
