@@ -1208,7 +1208,7 @@ void prefill_chunk_f16(Dev* d, const int* tokens, int bc, int pos0) {
 }  // namespace
 
 /* Prompt ingestion: what completion()'s prompt loop (src/completion.c:57-66) does with n calls of
- * forward(), 16 positions at a time on the matrix cores.  Leaves the KV cache and the returned logits
+ * forward(), up to 64 positions at a time on the matrix cores.  Leaves the KV cache and the returned logits
  * (those of the last prompt token, in m->state.logits) bit-identical to the n calls. */
 float* q3_prefill(Model* m, const int* tokens, int n, int pos0) {
     Dev* d = attach(m);

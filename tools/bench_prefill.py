@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prompt ingestion rate of q3_prefill (16 positions per pass, int8 MFMA) next to feeding the same
+"""Prompt ingestion rate of q3_prefill (up to 64 positions per pass, int8 MFMA) next to feeding the same
 prompt through forward() token by token, Qwen3-4B shapes.  usage: bench_prefill.py [prompt_len]"""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
