@@ -246,7 +246,10 @@ __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ 
                                                      const float* __restrict__ xs, int ntok,
                                                      float* __restrict__ out, int ldo, int ntiles) {
     constexpr int R = 16 * RT;
-    constexpr int A_BYTES = R * 512, B_BYTES = 64 * 512, WS_BYTES = 8 * R * 4, XS_BYTES = 8 * 64 * 4;
+    // scales in LDS: [group][row] and [group][token] with a group stride of 72 floats (= 8 mod 64): the fetch
+    // waves write them 8 groups x 8 rows per wave, which then lands in 64 different banks
+    constexpr int SS = 72;
+    constexpr int A_BYTES = R * 512, B_BYTES = 64 * 512, WS_BYTES = 8 * SS * 4, XS_BYTES = 8 * SS * 4;
     constexpr int OFF_B = A_BYTES, OFF_WS = A_BYTES + B_BYTES, OFF_XS = OFF_WS + WS_BYTES;
     constexpr int STAGE = OFF_XS + XS_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
@@ -298,9 +301,9 @@ __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ 
             for (int k = 0; k < 8; k++) {
                 if (prow + 8 * k < ntok16) *reinterpret_cast<v4i*>(base + OFF_B + slab_off(prow + 8 * k, piece)) = r.b[k];
             }
-            if (t < 8 * R) reinterpret_cast<float*>(base + OFF_WS)[(t & 7) * R + (t >> 3)] = r.ws;
+            if (t < 8 * R) reinterpret_cast<float*>(base + OFF_WS)[(t & 7) * SS + (t >> 3)] = r.ws;
 #pragma unroll
-            for (int k = 0; k < 2; k++) reinterpret_cast<float*>(base + OFF_XS)[(t & 7) * 64 + (t >> 3) + 32 * k] = r.xs[k];
+            for (int k = 0; k < 2; k++) reinterpret_cast<float*>(base + OFF_XS)[(t & 7) * SS + (t >> 3) + 32 * k] = r.xs[k];
         };
         GemmSlab<RT> S0, S1, S2;                                 // three slabs in flight
         fetch(S0);
@@ -341,11 +344,11 @@ __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ 
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             const v4i b = *reinterpret_cast<const v4i*>(base + OFF_B + slab_off(brow, 4 * g + kb));
-            const float sx = *reinterpret_cast<const float*>(base + OFF_XS + (g * 64 + brow) * 4);
+            const float sx = *reinterpret_cast<const float*>(base + OFF_XS + (g * SS + brow) * 4);
 #pragma unroll
             for (int r = 0; r < RT; r++) {
                 const v4i a = *reinterpret_cast<const v4i*>(base + slab_off(r * 16 + li, 4 * g + kb));
-                const float4 sw = *reinterpret_cast<const float4*>(base + OFF_WS + (g * R + r * 16 + 4 * kb) * 4);
+                const float4 sw = *reinterpret_cast<const float4*>(base + OFF_WS + (g * SS + r * 16 + 4 * kb) * 4);
                 const v4i32 zero = {0, 0, 0, 0};
                 const v4i32 dd = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, zero, 0, 0, 0);
                 const float swv[4] = {sw.x, sw.y, sw.z, sw.w};
