@@ -387,6 +387,11 @@ def main():
         # the roofline is quoted against the vendor HBM peak; next to it, what a plain device copy reaches here
         copy = hip.q3_measure_copy_gbps(1 << 30, 8)
         out["hbm_copy_gbps_measured"] = round(copy, 1)
+        if args.model == "4B":
+            # context for `value`: what the platform charges for this step's 182 dependent launches when every launch
+            # only streams its stage's bytes (tools/micro/chain_floor.hip) -- a committed measurement, not re-run here
+            out["dependent_launch_floor"] = {"us_per_token": [1012, 1061], "tokens_per_s": [942, 988],
+                                             "source": "profiles/r02_chain_floor.log (six launch shapes, one MI355X)"}
         out["frac_of_measured_copy"] = round(per_gpu_rate * bpt / 1e9 / copy, 4)
         hip.q3_prof_enable(m, 1)
         hip.q3_prof_reset(m)
