@@ -169,3 +169,29 @@ def test_classifier_loop_kernel_at_full_vocabulary(hip, orc, n):
     Q.record_parity(f"classifier_gemv_n{n}_d{d}", {"bit_exact_vs_tree": bool(np.array_equal(out, tree)), "rel_vs_reference_order": rel})
     assert np.array_equal(out, tree)
     assert rel <= 1e-6
+
+
+def test_4b_prompt_pass_equals_token_by_token(hip):
+    """full-size 4B: a 200-token prompt through q3_prefill (LDS-staged int8-MFMA GEMMs at every layer width,
+    block attention over 1-4 chunks) leaves the logits and the next decode steps bit-identical to 200 calls
+    of forward() -- which tier D ties to the tree oracle"""
+    path = os.path.join(Q.tmp_dir(), "4B.bin")
+    Q.synth("4B", path)
+    ma = hip.q3_model_open(path.encode(), 512, 0)
+    mb = hip.q3_model_open(path.encode(), 512, 0)
+    n = 200
+    prompt = np.random.default_rng(21).integers(0, 151936, size=n).astype(np.int32)
+    arr = (C.c_int * n)(*[int(t) for t in prompt])
+    la = Q.logits_array(ma, hip.q3_prefill(ma, arr, n, 0))
+    for pos in range(n):
+        lb = Q.logits_array(mb, hip.forward(mb, int(prompt[pos]), pos))
+    assert np.array_equal(la, lb)
+    tok = int(la.argmax())
+    for pos in range(n, n + 4):
+        la = Q.logits_array(ma, hip.forward(ma, tok, pos))
+        lb = Q.logits_array(mb, hip.forward(mb, tok, pos))
+        assert np.array_equal(la, lb), pos
+        tok = int(la.argmax())
+    Q.record_parity("prefill_4B_200_tokens", {"bit_identical_to_token_by_token": True, "decode_steps_after": 4})
+    hip.q3_model_close(ma)
+    hip.q3_model_close(mb)
