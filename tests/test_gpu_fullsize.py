@@ -141,6 +141,17 @@ def test_full_size_configs_bit_exact_vs_tree_oracle(hip, host, orc, name):
         assert np.array_equal(a, b), f"{name} pos {pos}: max diff {np.abs(a - b).max()}"
     orc.orc_set_threads(1)
     Q.record_parity(f"{name}_vs_tree_oracle", {"positions": len(feed), "max_abs_diff": worst, "bit_exact": True})
+    # the batched prompt pass at these widths (GEMM slabs of n = 2048 / 4096 and 6144 / 12288, both tile widths):
+    # 40 tokens through q3_prefill on a second handle == 40 calls of forward() on the first
+    mp = hip.q3_model_open(path.encode(), 64, 0)
+    prompt = np.random.default_rng(29).integers(0, 151936, size=40).astype(np.int32)
+    arr = (C.c_int * 40)(*[int(t) for t in prompt])
+    lp = Q.logits_array(mp, hip.q3_prefill(mp, arr, 40, 0))
+    for pos in range(40):
+        lf = Q.logits_array(mg, hip.forward(mg, int(prompt[pos]), pos))
+    assert np.array_equal(lp, lf), f"{name}: prompt pass differs from token-by-token decode"
+    Q.record_parity(f"prefill_{name}_40_tokens", {"bit_identical_to_token_by_token": True})
+    hip.q3_model_close(mp)
     hip.q3_model_close(mg); host.q3_model_close(mo)
 
 
