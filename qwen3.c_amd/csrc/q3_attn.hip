@@ -859,7 +859,10 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st) {
     }
     const int nz = a.nz > 1 ? a.nz : 1;
     const bool two = a.n_heads / a.n_kv > 4;
-    const int slots = mode == ATT_SINGLE ? 1 : chunk_slots;
+    // ATT_MERGE serves positions below Q3_ATT_LONG only: never more than Q3_ATT_LONG / 64 chunks, so the
+    // launch need not dispatch (and retire) workgroups for slots that can have no chunk
+    const int merge_slots = chunk_slots < Q3_ATT_LONG / Q3_ATT_CHUNK ? chunk_slots : Q3_ATT_LONG / Q3_ATT_CHUNK;
+    const int slots = mode == ATT_SINGLE ? 1 : (mode == ATT_MERGE ? merge_slots : chunk_slots);
     if (nz > 1) {
         // a pass of the batched prompt path: blocks of positions share a staged tile; as many positions
         // per block as still leaves ~2 workgroups per CU
