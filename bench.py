@@ -93,6 +93,40 @@ def cpu_baseline(path, vocab, budget_s=20.0):
                                                      if kind == "reference" else "")}
 
 
+def chain_floor_from_log(path):
+    """The committed measurement of tools/micro/chain_floor.hip: per launch shape, microseconds per
+    token-equivalent of a hipGraph of this step's dependent launches that only stream their bytes."""
+    import re
+    try:
+        us = [float(x) for x in re.findall(r"launches, ([0-9.]+) us per token-equivalent", open(path).read())]
+    except OSError:
+        return None
+    if not us:
+        return None
+    return {"us_per_token": [round(min(us), 1), round(max(us), 1)],
+            "tokens_per_s": [round(1e6 / max(us), 1), round(1e6 / min(us), 1)],
+            "source": f"{os.path.relpath(path, ROOT)} ({len(us)} launch shapes, one MI355X; committed, not re-run here)"}
+
+
+def job_nonce():
+    """8 bytes that every rank of THIS job agrees on and another job does not share: the launcher's run id
+    (torch.distributed.run exports TORCHELASTIC_RUN_ID to every worker; spawn_ranks exports Q3_JOB_NONCE), hashed.
+    Without either (a hand-rolled launcher) the tag is the same for every job and only the mtime window and
+    rank 0's unlink after the rendezvous keep an old file out."""
+    import hashlib
+    key = os.environ.get("Q3_JOB_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    return hashlib.sha256(key.encode()).digest()[:8]
+
+
+def unlink_id_file(world, tmp):
+    """Rank 0, after the barrier that proves every rank holds the id: the file must not outlive the rendezvous."""
+    port = int(os.environ.get("MASTER_PORT", "0"))
+    try:
+        os.remove(os.path.join(tmp, f"rccl_id_{port}_{world}"))
+    except OSError:
+        pass
+
+
 def share_id(rank, world, payload, tmp, timeout_s=300.0):
     """Rank 0 hands `payload` (the 128-byte RCCL unique id) to the other ranks of this node.  First choice: a
     TCP exchange on MASTER_ADDR:MASTER_PORT (nothing else of this job uses that port: torch.distributed is not
@@ -101,7 +135,7 @@ def share_id(rank, world, payload, tmp, timeout_s=300.0):
     import socket
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(os.environ.get("MASTER_PORT", "0"))
-    tag = b"Q3ID" + bytes([world & 255])
+    tag = b"Q3ID" + bytes([world & 255]) + job_nonce()
     idfile = os.path.join(tmp, f"rccl_id_{port}_{world}")
     started = time.time()
     if rank == 0:
@@ -174,20 +208,48 @@ def spawn_ranks(n):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    nonce = f"{os.getpid()}-{time.time_ns()}"
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), Q3_BENCH_CHILD="1")
+                   MASTER_PORT=str(port), Q3_BENCH_CHILD="1", Q3_JOB_NONCE=nonce)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    line, _ = procs[0].communicate()
-    bad = [r for r, pr in enumerate(procs) if pr.wait() != 0]
+    line, bad = supervise(procs, float(os.environ.get("Q3_BENCH_TIMEOUT", "900")) + 60.0)
+    if bad:
+        raise SystemExit(f"[bench] rank(s) {bad} failed")
+    sys.stdout.write(line)
+    sys.stdout.flush()
+
+
+def supervise(procs, timeout_s):
+    """Watch ALL rank processes: as soon as one exits non-zero, or the deadline passes, the others are killed
+    (a rank that died would otherwise leave its peers blocked in the RCCL rendezvous, holding the GPUs).
+    Rank 0's stdout is drained on a thread so that a long line cannot block it.  Returns (rank 0's stdout,
+    list of failed ranks)."""
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + timeout_s
+    bad = []
+    while True:
+        codes = [pr.poll() for pr in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad or all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            bad = [r for r, c in enumerate(codes) if c is None]
+            log(f"[bench] ranks {bad} still running after {timeout_s:.0f}s: killing them")
+            break
+        time.sleep(0.05)
     if bad:
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
-        raise SystemExit(f"[bench] rank(s) {bad} failed")
-    sys.stdout.write(line)
-    sys.stdout.flush()
+    for pr in procs:
+        pr.wait()
+    reader.join(10.0)
+    return "".join(c or "" for c in chunks), bad
 
 
 def main():
@@ -241,6 +303,8 @@ def main():
         assert hip.q3_pipeline_init(rank, ngpu, raw) == 0
         assert hip.q3_pipeline_size() == ngpu, (hip.q3_pipeline_size(), ngpu)
         hip.q3_pipeline_allreduce_max(0.0)            # everybody has joined
+        if rank == 0:
+            unlink_id_file(ngpu, Q.tmp_dir())
 
     tmp = Q.tmp_dir()
     path = os.path.join(tmp, f"{args.model}.bin")
@@ -278,6 +342,22 @@ def main():
         hip.q3_device_sync(m)
         elapsed = time.perf_counter() - t0
         total_tokens = K
+        # `value` is the K steps the caller asked for.  A short K stays inside the cheapest attention launch
+        # shape (fewer than 64 cached positions), so the same loop is ALSO timed over 20 and over 256 steps from
+        # position pos0 + W, whatever K is, and both rates go into the line (`by_steps`).
+        by_steps = {}
+        for ks in (20, 256):
+            if ks == K:
+                by_steps[str(ks)] = round(K / elapsed, 2)
+                continue
+            if pos0 + W + ks + 8 > seq:
+                continue
+            t_tok, t_pos = run(W, START_TOKEN % vocab, pos0)
+            hip.q3_device_sync(m)
+            t1 = time.perf_counter()
+            run(ks, t_tok, t_pos)
+            hip.q3_device_sync(m)
+            by_steps[str(ks)] = round(ks / (time.perf_counter() - t1), 2)
     else:
         # N streams x (W + K) tokens: untimed fill + warm-up, then K timed tokens per stream
         first = START_TOKEN % vocab
@@ -290,6 +370,15 @@ def main():
         elapsed = hip.q3_pipeline_allreduce_max(time.perf_counter() - t0)
         total_tokens = K * ngpu
         tok, pos = first, pos0 + W + K
+        # ONE token stream through the N stages (each stage busy one tick in N, a hand-off per
+        # stage and token) -- the figure a single user sees; its roofline is ONE GPU's (only one is busy)
+        hip.q3_pipeline_run_streams(m, first, pos0, W, 1)
+        hip.q3_device_sync(m)
+        hip.q3_pipeline_allreduce_max(0.0)
+        t0 = time.perf_counter()
+        hip.q3_pipeline_run_streams(m, first, pos0 + W, K, 1)
+        hip.q3_device_sync(m)
+        single_elapsed = hip.q3_pipeline_allreduce_max(time.perf_counter() - t0)
 
     out = {
         "metric": "decode tokens/sec Qwen3-4B Q8_0" if args.model == "4B" else f"decode tokens/sec Qwen3-{args.model} Q8_0",
@@ -324,6 +413,17 @@ def main():
     per_gpu_rate = out["value"] / ngpu
     out["hbm_roofline_frac_step"] = round(per_gpu_rate * bpt / 1e9 / HBM_PEAK_GBS * (1 if ngpu == 1 else 1.0), 4)
     out["bytes_per_token"] = int(bpt)
+    if ngpu == 1:
+        out["by_steps"] = {"tokens_per_s": by_steps,
+                           "note": "the same decode loop timed over 20 and over 256 steps from the same start position: a "
+                                   "20-step run never leaves the one-chunk attention launch shape (< 64 cached positions)"}
+    else:
+        single = K / single_elapsed
+        out["single_stream"] = {"tokens_per_s": round(single, 2), "ms_per_token": round(1000.0 * single_elapsed / K, 4),
+                                "frac_of_one_gpu_hbm_roofline": round(single * bpt / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": f"one token stream through the {ngpu} stages (q3_pipeline_run_streams(..., 1)): stages "
+                                        "run one after the other, so the roofline it is quoted against is ONE GPU's; `value` is "
+                                        f"the aggregate of {ngpu} concurrent streams"}
 
     if ngpu == 1:
         # the same decode loop kept on the device (argmax feeds the next step, no D2H per token)
@@ -378,11 +478,15 @@ def main():
         # reported next to the decode rate, not part of `value`
         n_pf = 256
         prompt = (C.c_int * n_pf)(*[int(t) for t in np.random.default_rng(5).integers(0, vocab, size=n_pf)])
-        hip.q3_prefill(m, prompt, 32, 0)
-        t0 = time.perf_counter()
-        hip.q3_prefill(m, prompt, n_pf, 0)             # a prompt from position 0 (the rows it rewrites stay finite)
-        out["prefill_tokens_per_s"] = round(n_pf / (time.perf_counter() - t0), 1)
+        hip.q3_prefill(m, prompt, n_pf, 0)             # untimed: first use of every launch shape of this prompt
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            hip.q3_prefill(m, prompt, n_pf, 0)         # a prompt from position 0 (the rows it rewrites stay finite)
+            times.append(time.perf_counter() - t0)
+        out["prefill_tokens_per_s"] = round(n_pf / sorted(times)[1], 1)
         out["prefill_prompt_tokens"] = n_pf
+        out["prefill_timing"] = "median of 3 passes after one untimed pass of the same prompt"
     if rank == 0 and ngpu == 1 and not args.no_roofline and args.dtype == "q8":
         # the roofline is quoted against the vendor HBM peak; next to it, what a plain device copy reaches here
         copy = hip.q3_measure_copy_gbps(1 << 30, 8)
@@ -390,8 +494,9 @@ def main():
         if args.model == "4B":
             # context for `value`: what the platform charges for this step's 182 dependent launches when every launch
             # only streams its stage's bytes (tools/micro/chain_floor.hip) -- a committed measurement, not re-run here
-            out["dependent_launch_floor"] = {"us_per_token": [1012, 1061], "tokens_per_s": [942, 988],
-                                             "source": "profiles/r02_chain_floor.log (six launch shapes, one MI355X)"}
+            floor = chain_floor_from_log(os.path.join(ROOT, "profiles", "r02_chain_floor.log"))
+            if floor:
+                out["dependent_launch_floor"] = floor
         out["frac_of_measured_copy"] = round(per_gpu_rate * bpt / 1e9 / copy, 4)
         hip.q3_prof_enable(m, 1)
         hip.q3_prof_reset(m)

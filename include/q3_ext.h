@@ -203,14 +203,25 @@ void q3_pipeline_layers(const ModelParams* p, int rank, int world, int* first, i
 int q3_pipeline_schedule(int rank, int world, int nsteps, int tick, int* stream, int* k);
 /* Greedy-decode `nsteps` tokens of every stream on the device(s), all streams starting
  * from `first_token` at position pos0.  Asynchronous: returns after enqueueing; follow
- * with q3_device_sync().  With world == 1 this is the on-device greedy loop. */
+ * with q3_device_sync().  With world == 1 this is the on-device greedy loop.
+ * Returns the number of ticks on which THIS rank computed: nsteps * world (every rank
+ * handles every token of every stream once); it exits with a message on bad arguments,
+ * so there is no error value. */
 int q3_pipeline_run(Model* m, int first_token, int pos0, int nsteps);
+/* The same with only the first `streams` of the `world` streams running (0 or >= world: all).  The tick
+ * schedule does not change -- the ticks of a stream that does not run stay idle -- so streams = 1 is ONE
+ * token stream travelling through the stages with a hand-off per stage and token (a single
+ * stream gains capacity from the pipeline, not speed).  Returns nsteps * streams. */
+int q3_pipeline_run_streams(Model* m, int first_token, int pos0, int nsteps, int streams);
 /* Tokens stream `stream` chose in the last q3_pipeline_run (valid on the last rank). */
 int q3_pipeline_tokens(Model* m, int stream, int* out, int n);
 /* Single-GPU self-test of the pipeline code: `world` stages in one process, hand-offs by
  * device copies instead of RCCL.  out_tokens[world][nsteps].  Returns 0 on success. */
 int q3_pipeline_selftest(const char* path, int seq_len, int world, int first_token, int pos0,
                          int nsteps, int* out_tokens);
+/* ... with only the first `streams` streams running (0 = all): out_tokens[streams][nsteps] */
+int q3_pipeline_selftest_streams(const char* path, int seq_len, int world, int streams, int first_token,
+                                 int pos0, int nsteps, int* out_tokens);
 /* max over ranks (doubles as a barrier) */
 double q3_pipeline_allreduce_max(double v);
 void q3_pipeline_shutdown(void);

@@ -51,9 +51,12 @@ void swiglu(float* x1, float* x3, int size);
 
 /* reference include/forward.h:124 / src/forward.c:141-195.
  * Attention of layer `layer` for the query at `pos` over cached positions
- * 0..pos.  Operates on the Model's device-resident q / KV cache (filled by the
- * QKV stage of forward()); when m->state.x_rms_norm is non-NULL the head
- * outputs are also copied there, as the reference leaves them. */
+ * 0..pos, with the reference's HOST-state semantics: reads m->state.q (already
+ * normed and rotated by the caller) and rows 0..pos of the layer's host
+ * k_cache / v_cache, writes the head outputs to m->state.x_rms_norm.  It
+ * neither norms, rotates nor appends, and does not touch the device-resident
+ * cache forward() keeps.  A Model opened without host state (no q / KV cache
+ * arrays) makes it print a message and exit: there is nothing to read. */
 void attention(Model* m, int layer, int pos);
 
 /* reference include/q8.h:25,30 / src/q8.c:5-37. */

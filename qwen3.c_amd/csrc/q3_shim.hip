@@ -1061,15 +1061,19 @@ void pipeline_check(Dev* d, int first_token, int pos0, int nsteps) {
     if (d->rank == d->world - 1) ensure_token_log(d, nsteps);
 }
 
-// Runs `nsteps` tokens of every stream, starting from `first_token` at `pos0`.
+// Runs `nsteps` tokens of the first `streams` streams (0 or >= world: all of them), starting from
+// `first_token` at `pos0`.  The tick schedule is the same whatever `streams` is -- a stream that does not
+// run leaves its ticks idle -- so streams = 1 is ONE token stream travelling through the stages, each
+// stage busy on one tick in `world` (the single-stream figure).
 // Returns the number of ticks on which this rank computed.
-int pipeline_run(Dev* d, int first_token, int pos0, int nsteps) {
+int pipeline_run(Dev* d, int first_token, int pos0, int nsteps, int streams = 0) {
     pipeline_check(d, first_token, pos0, nsteps);
+    if (streams <= 0 || streams > d->world) streams = d->world;
     int ticks = 0;
     const int T = nsteps * d->world + d->world - 1;
     for (int t = 0; t < T; t++) {
         int s = 0, k = 0;
-        if (q3_pipeline_schedule(d->rank, d->world, nsteps, t, &s, &k)) {
+        if (q3_pipeline_schedule(d->rank, d->world, nsteps, t, &s, &k) && s < streams) {
             pipeline_tick(d, first_token, pos0, s, k);
             ticks++;
         }
@@ -1085,6 +1089,11 @@ extern "C" {
 int q3_pipeline_run(Model* m, int first_token, int pos0, int nsteps) {
     Dev* d = attach(m);
     return pipeline_run(d, first_token, pos0, nsteps);
+}
+
+int q3_pipeline_run_streams(Model* m, int first_token, int pos0, int nsteps, int streams) {
+    Dev* d = attach(m);
+    return pipeline_run(d, first_token, pos0, nsteps, streams);
 }
 
 // Tokens chosen by stream `stream` in the last q3_pipeline_run (valid on the last rank).
@@ -1693,9 +1702,17 @@ void q3_op_expf(const float* x, int n, float* out) {
 // copies.  Everything else -- layer split, per-stream KV caches, tick schedule, token
 // feedback, graphs -- is the code the multi-process run executes.
 // out_tokens[world][nsteps]; returns 0 on success.
+int q3_pipeline_selftest_streams(const char* path, int seq_len, int world, int streams, int first_token, int pos0,
+                                 int nsteps, int* out_tokens);
 int q3_pipeline_selftest(const char* path, int seq_len, int world, int first_token, int pos0, int nsteps,
                          int* out_tokens) {
+    return q3_pipeline_selftest_streams(path, seq_len, world, 0, first_token, pos0, nsteps, out_tokens);
+}
+// the same with only the first `streams` streams running (0 = all): out_tokens[streams][nsteps]
+int q3_pipeline_selftest_streams(const char* path, int seq_len, int world, int streams, int first_token, int pos0,
+                                 int nsteps, int* out_tokens) {
     if (world < 1 || world > 64) return -1;
+    if (streams <= 0 || streams > world) streams = world;
     std::vector<Model*> ms(world, nullptr);
     std::vector<Dev*> ds(world, nullptr);
     for (int r = 0; r < world; r++) {
@@ -1719,7 +1736,7 @@ int q3_pipeline_selftest(const char* path, int seq_len, int world, int first_tok
     for (int t = 0; t < T; t++) {
         for (int r = 0; r < world; r++) {
             int s = 0, k = 0;
-            if (q3_pipeline_schedule(r, world, nsteps, t, &s, &k)) pipeline_tick(ds[r], first_token, pos0, s, k);
+            if (q3_pipeline_schedule(r, world, nsteps, t, &s, &k) && s < streams) pipeline_tick(ds[r], first_token, pos0, s, k);
         }
         if (t < T - 1) {
             for (int r = 0; r < world; r++) ring_exchange(ds[r], t);     // sends
@@ -1727,7 +1744,7 @@ int q3_pipeline_selftest(const char* path, int seq_len, int world, int first_tok
         }
     }
     HIPCHK(hipStreamSynchronize(ds[0]->st));
-    for (int s = 0; s < world; s++) q3_pipeline_tokens(ms[world - 1], s, out_tokens + (size_t)s * nsteps, nsteps);
+    for (int s = 0; s < streams; s++) q3_pipeline_tokens(ms[world - 1], s, out_tokens + (size_t)s * nsteps, nsteps);
     for (int r = world - 1; r >= 0; r--) {
         if (r > 0) HIPCHK(hipStreamCreateWithFlags(&ds[r]->st, hipStreamNonBlocking));   // detach destroys it
         q3_model_close(ms[r]);

@@ -1,5 +1,5 @@
-// q3_tile.hpp -- the unit of weight streaming shared by the GEMV launches (q3_gemv.hip)
-// and the persistent step kernel (q3_mega.hip): a TILE is R consecutive rows of a Q8_0
+// q3_tile.hpp -- the unit of weight streaming of the GEMV launches (q3_gemv.hip; also used
+// by the fp16 and prompt-pass kernels): a TILE is R consecutive rows of a Q8_0
 // matrix as seen by one wave -- R*NJ wave-loads of 1 KiB codes (lane l holds bytes
 // [1024 j + 16 l, +16) of each row) plus the group scales each quad needs.
 //

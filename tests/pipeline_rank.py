@@ -33,7 +33,8 @@ def main():
     assert hip.q3_pipeline_init(rank, world, open(idfile, "rb").read()) == 0
     assert hip.q3_pipeline_size() == world
     m = hip.q3_model_open(path.encode(), 256, 0)
-    assert hip.q3_pipeline_run(m, 11, 0, n) == 0
+    ticks = hip.q3_pipeline_run(m, 11, 0, n)
+    assert ticks == n * world, ticks          # ticks this rank computed on (include/q3_ext.h)
     hip.q3_device_sync(m)
     if rank == world - 1:
         streams = []

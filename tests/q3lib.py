@@ -212,6 +212,10 @@ def hip_lib():
         lib.q3_pipeline_schedule.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.q3_pipeline_run.restype = C.c_int
         lib.q3_pipeline_run.argtypes = [ModelP, C.c_int, C.c_int, C.c_int]
+        lib.q3_pipeline_run_streams.restype = C.c_int
+        lib.q3_pipeline_run_streams.argtypes = [ModelP, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.q3_pipeline_selftest_streams.restype = C.c_int
+        lib.q3_pipeline_selftest_streams.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         lib.q3_pipeline_tokens.restype = C.c_int
         lib.q3_pipeline_tokens.argtypes = [ModelP, C.c_int, C.POINTER(C.c_int), C.c_int]
         lib.q3_pipeline_selftest.restype = C.c_int

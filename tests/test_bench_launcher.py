@@ -69,3 +69,40 @@ def test_rccl_id_falls_back_to_the_file_when_the_port_is_taken(tmp_path):
             p.join(30)
             assert p.exitcode == 0
     assert got[1] == payload
+
+
+def test_launcher_kills_the_other_ranks_when_one_dies():
+    """bench.supervise: a rank that exits non-zero must not leave its peers waiting in the RCCL
+    rendezvous -- the survivors are killed and the failure is reported, well inside the overall timeout."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    sleeper = [sys.executable, "-c", "import time; print('line', flush=True); time.sleep(120)"]
+    dier = [sys.executable, "-c", "import sys, time; time.sleep(0.5); sys.exit(3)"]
+    procs = [subprocess.Popen(sleeper, stdout=subprocess.PIPE, text=True), subprocess.Popen(dier),
+             subprocess.Popen(sleeper, stdout=subprocess.DEVNULL)]
+    t0 = time.time()
+    line, bad = bench.supervise(procs, 60.0)
+    assert bad == [1] and time.time() - t0 < 20.0
+    assert all(p.poll() is not None for p in procs)
+    assert "line" in line
+
+
+def test_launcher_times_out_hung_ranks():
+    sys.path.insert(0, ROOT)
+    import bench
+    sleeper = [sys.executable, "-c", "import time; time.sleep(120)"]
+    procs = [subprocess.Popen(sleeper, stdout=subprocess.PIPE, text=True), subprocess.Popen(sleeper)]
+    _line, bad = bench.supervise(procs, 1.0)
+    assert bad == [0, 1]
+    assert all(p.poll() is not None for p in procs)
+
+
+def test_id_file_of_another_job_is_not_accepted(tmp_path, monkeypatch):
+    """file fallback: an id file left by a job with a different launcher nonce carries a different tag"""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("Q3_JOB_NONCE", "job-a")
+    a = bench.job_nonce()
+    monkeypatch.setenv("Q3_JOB_NONCE", "job-b")
+    assert bench.job_nonce() != a and len(a) == 8

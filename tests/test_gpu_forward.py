@@ -125,6 +125,23 @@ def test_pipeline_selftest_matches_single_gpu(hip, host, world):
         assert list(got[s * nsteps:(s + 1) * nsteps]) == list(want), f"stream {s}"
 
 
+@pytest.mark.parametrize("world,streams", [(4, 1), (3, 2)])
+def test_pipeline_selftest_with_fewer_streams_than_stages(hip, world, streams):
+    """q3_pipeline_run_streams' schedule (bench.py's single-stream figure at N > 1): only the first `streams`
+    streams run, the others' ticks stay idle, the stale messages of idle ticks are never consumed."""
+    path = os.path.join(Q.tmp_dir(), "small.bin")
+    Q.synth("small", path)
+    mg = hip.q3_model_open(path.encode(), 0, 0)
+    nsteps = 20
+    want = (C.c_int * nsteps)()
+    assert hip.q3_generate_greedy(mg, 7, 0, nsteps, want) == nsteps
+    hip.q3_model_close(mg)
+    got = (C.c_int * (streams * nsteps))()
+    assert hip.q3_pipeline_selftest_streams(path.encode(), 0, world, streams, 7, 0, nsteps, got) == 0
+    for s in range(streams):
+        assert list(got[s * nsteps:(s + 1) * nsteps]) == list(want), f"stream {s}"
+
+
 def test_pipeline_schedule_covers_every_token_once(hip):
     for world in (1, 2, 4, 8):
         nsteps = 5

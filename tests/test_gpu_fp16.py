@@ -62,5 +62,7 @@ def test_fp16_prefill_on_the_matrix_cores(hip, host, orc, name, n):
     err_next = float(np.abs(lg2 - lo2).max() / np.abs(lo2).max())
     orc.orc_set_threads(1)
     Q.record_parity(f"fp16_mfma_prefill_{name}", {"prompt": n, "rel_err_after_prompt": err_prefill, "rel_err_next_decode_step": err_next})
-    assert np.isfinite(lg).all() and err_prefill <= 2e-2 and err_next <= 2e-2, (err_prefill, err_next)
+    # bar: 3e-3 (recorded errors are <= 8.5e-4, profiles/parity_r02.json; a dropped k-step or a wrong tile edge moves the
+    # logits by percents, which the former 2e-2 bar would have let through -- ADVICE r2)
+    assert np.isfinite(lg).all() and err_prefill <= 3e-3 and err_next <= 3e-3, (err_prefill, err_next)
     hip.q3_model_close(mg); host.q3_model_close(mo)

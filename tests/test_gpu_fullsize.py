@@ -206,3 +206,36 @@ def test_4b_prompt_pass_equals_token_by_token(hip):
     Q.record_parity("prefill_4B_200_tokens", {"bit_identical_to_token_by_token": True, "decode_steps_after": 4})
     hip.q3_model_close(ma)
     hip.q3_model_close(mb)
+
+
+@pytest.mark.parametrize("name,world", [("8B", 2), ("8B", 4), ("8B", 8), ("4B", 8)])
+def test_full_size_pipeline_selftest_matches_single_gpu(hip, name, world):
+    """BASELINE config 4 on its own shapes: the layer pipeline on full-size DeepSeek-R1-0528-Qwen3-8B-shaped
+    weights (untied classifier on the last stage only, embedding on the first) as 2 / 4 / 8 stages -- the 8-stage
+    split is 5/5/5/5/5/4/4/3 -- and on tied 4B as 8 stages (embedding matrix on the first AND the last stage).
+    All stages live in this one process (q3_pipeline_selftest: the stage split, per-stream KV caches, tick
+    schedule, token feedback and graphs are the code the RCCL run executes; the hand-offs are device copies),
+    and every one of the `world` streams must reproduce the single-GPU greedy tokens."""
+    path = os.path.join(Q.tmp_dir(), f"{name}.bin")
+    Q.synth(name, path)
+    nsteps = 12
+    mg = hip.q3_model_open(path.encode(), 128, 0)
+    p = mg.contents.params
+    counts = []
+    for r in range(world):
+        first, count = C.c_int(), C.c_int()
+        hip.q3_pipeline_layers(C.byref(p), r, world, C.byref(first), C.byref(count))
+        assert first.value == sum(counts)
+        counts.append(count.value)
+    assert sum(counts) == p.n_layers and min(counts) >= 1
+    if (name, world) == ("8B", 8):
+        assert counts == [5, 5, 5, 5, 5, 4, 4, 3]
+    want = (C.c_int * nsteps)()
+    assert hip.q3_generate_greedy(mg, 9707, 0, nsteps, want) == nsteps
+    hip.q3_model_close(mg)
+    got = (C.c_int * (world * nsteps))()
+    assert hip.q3_pipeline_selftest(path.encode(), 128, world, 9707, 0, nsteps, got) == 0
+    for s in range(world):
+        assert list(got[s * nsteps:(s + 1) * nsteps]) == list(want), f"{name} world {world} stream {s}"
+    Q.record_parity(f"pipeline_selftest_{name}_world{world}", {"layers_per_stage": counts, "tokens_per_stream": nsteps,
+                                                              "streams_equal_single_gpu": True})
