@@ -345,6 +345,40 @@ void orc_attention(Model* m, int layer, int pos) {
                       p->n_kv_heads, p->head_dim, s->x_rms_norm);
 }
 
+/* Twin of the product's q3_kv_fill_random() (timing / long-context parity helper, no reference
+ * counterpart): rows 0..T-1 of every layer's K and V cache get the values the device kernel
+ * k_fill_random writes -- splitmix64 of (seed_lg + i * golden), top 24 bits mapped to [-1, 1) --
+ * where i = t * head_dim + j indexes (position, element) inside one (layer, kv head) and
+ * seed_lg = seed + 2 * (layer * 64 + kv_head) (+ 1 for V).  Written in the REFERENCE cache layout
+ * [layer][seq_len][n_kv][head_dim] (src/model.c:360-361, src/forward.c:148), so both sides then
+ * attend over the same numbers. */
+void orc_kv_fill_random(Model* m, int T, uint64_t seed) {
+    const ModelParams* p = &m->params;
+    ForwardState* s = &m->state;
+    const int hd = p->head_dim, KV = p->n_kv_heads;
+    const size_t kvd = (size_t)KV * hd;
+    if (T > p->seq_len) T = p->seq_len;
+#pragma omp parallel for num_threads(g_threads) schedule(static) collapse(2)
+    for (int l = 0; l < p->n_layers; l++) {
+        for (int g = 0; g < KV; g++) {
+            for (int which = 0; which < 2; which++) {
+                const uint64_t sd = seed + 2 * (uint64_t)(l * 64 + g) + (uint64_t)which;
+                float* base = (which ? s->v_cache : s->k_cache) + (size_t)l * p->seq_len * kvd + (size_t)g * hd;
+                for (int t = 0; t < T; t++) {
+                    for (int j = 0; j < hd; j++) {
+                        const uint64_t i = (uint64_t)t * hd + j;
+                        uint64_t z = sd + i * 0x9E3779B97F4A7C15ull;
+                        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                        z ^= z >> 31;
+                        base[(size_t)t * kvd + j] = ((float)(z >> 40) * (1.0f / 16777216.0f) - 0.5f) * 2.0f;
+                    }
+                }
+            }
+        }
+    }
+}
+
 /* ---------------------------------------------------------- forward ---- */
 
 /* reference src/forward.c:225-350.  Needs a Model with host state

@@ -279,6 +279,8 @@ def oracle_lib():
         lib.orc_forward.restype = c_float_p
         lib.orc_forward.argtypes = [ModelP, C.c_int, C.c_int]
         lib.orc_layer_step.argtypes = [ModelP, C.c_int, C.c_int, c_float_p, c_float_p]
+        lib.orc_kv_fill_random.restype = None
+        lib.orc_kv_fill_random.argtypes = [ModelP, C.c_int, C.c_uint64]
         lib.orc_forward_f16.restype = c_float_p
         lib.orc_forward_f16.argtypes = [ModelP, C.c_int, C.c_int]
         lib.orc_xorshift_float.restype = C.c_float

@@ -292,3 +292,25 @@ def test_exported_attention_has_the_reference_semantics(hip, host, orc):
     assert np.array_equal(np.ctypeslib.as_array(mg.contents.state.k_cache, shape=(p.n_layers, seq, KVD))[layer, :pos + 1], k)
     assert np.array_equal(np.ctypeslib.as_array(mg.contents.state.q, shape=(P,)), q)
     host.q3_model_close(mg); host.q3_model_close(mo)
+
+
+@pytest.mark.parametrize("name,T", [("small", 100), ("4Bmini", 700), ("4Bmini", 1500)])
+def test_decode_over_a_pseudo_random_cache_vs_oracle(hip, host, orc, name, T):
+    """q3_kv_fill_random and its oracle twin put the same rows into both caches (device layout
+    [kv head][position] vs the reference's [position][kv head]); three decode steps on top are bit-identical
+    to the tree oracle.  The small-model counterpart of test_gpu_fullsize.py::test_4b_long_context_vs_oracle."""
+    seq = T + 16
+    path = os.path.join(Q.tmp_dir(), f"{name}_w2048.bin")
+    Q.synth(name, path, seq_len=2048)           # the preset's weights with a longer window in the header
+    mg = hip.q3_model_open(path.encode(), seq, 0)
+    mo = host.q3_model_open(path.encode(), seq, 1)
+    hip.q3_kv_fill_random(mg, T, 5)
+    orc.orc_kv_fill_random(mo, T, 5)
+    orc.orc_set_mode(Q.ORC_TREE)
+    tok = 3
+    for k in range(3):
+        a = Q.logits_array(mg, hip.forward(mg, tok, T + k))
+        b = Q.logits_array(mo, orc.orc_forward(mo, tok, T + k))
+        assert np.array_equal(a, b), (name, T, k)
+        tok = int(a.argmax())
+    hip.q3_model_close(mg); host.q3_model_close(mo)

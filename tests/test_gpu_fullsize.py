@@ -239,3 +239,53 @@ def test_full_size_pipeline_selftest_matches_single_gpu(hip, name, world):
         assert list(got[s * nsteps:(s + 1) * nsteps]) == list(want), f"{name} world {world} stream {s}"
     Q.record_parity(f"pipeline_selftest_{name}_world{world}", {"layers_per_stage": counts, "tokens_per_stream": nsteps,
                                                               "streams_equal_single_gpu": True})
+
+
+@pytest.mark.parametrize("T", [512, 4096])
+def test_4b_long_context_vs_oracle(hip, host, orc, T):
+    """BASELINE config 3 at full size against the oracle (round-2 VERDICT: beyond position 4 the full-size 4B
+    had met the oracle only at op level and on a 2-layer model).  Both sides fill rows 0..T-1 of every layer's
+    K/V cache with the same pseudo-random values (q3_kv_fill_random on the device, its twin orc_kv_fill_random
+    in the reference's cache layout), then run two teacher-forced steps at positions T and T+1 through all 36
+    layers: logits bit-identical to the tree-order oracle.  Launch shapes: T = 512 -> in-launch merge of the
+    chunk partials, T = 4096 -> wide merge.  Then, on the last layer's own q and cache (reference
+    src/forward.c:141-195), the exported attention() against the REFERENCE-order restatement within
+    max(2e-6, 2e-9 * T) of max|out| -- the bar the op-level tests use (the slack is the reference's own
+    sequential fp32 sum over T terms)."""
+    path = os.path.join(Q.tmp_dir(), "4B.bin")
+    Q.synth("4B", path)
+    seq = T + 64
+    mg = hip.q3_model_open(path.encode(), seq, 0)
+    mo = host.q3_model_open(path.encode(), seq, 1)
+    orc.orc_set_threads(16)
+    hip.q3_kv_fill_random(mg, T, 99)
+    orc.orc_kv_fill_random(mo, T, 99)
+    orc.orc_set_mode(Q.ORC_TREE)
+    feed = np.random.default_rng(31 + T).integers(0, 151936, size=2)
+    for k, tok in enumerate(feed):
+        a = Q.logits_array(mg, hip.forward(mg, int(tok), T + k))
+        b = Q.logits_array(mo, orc.orc_forward(mo, int(tok), T + k))
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b), f"T={T} step {k}: max diff {np.abs(a - b).max()}"
+    # op level, reference order: the last layer's attention at position T+1 on the oracle's host state
+    p = mo.contents.params
+    P = p.n_heads * p.head_dim
+    layer, pos = p.n_layers - 1, T + 1
+    out = np.ctypeslib.as_array(mo.contents.state.x_rms_norm, (P,))
+    orc.orc_set_mode(Q.ORC_REF)
+    orc.orc_attention(mo, layer, pos)
+    ref = out.copy()
+    orc.orc_set_mode(Q.ORC_TREE)
+    orc.orc_attention(mo, layer, pos)
+    tree = out.copy()
+    hip.attention(mo, layer, pos)
+    got = out.copy()
+    orc.orc_set_threads(1)
+    rel = float(np.abs(got - ref).max() / np.abs(ref).max())
+    Q.record_parity(f"4B_at_{T}_cached_positions", {
+        "steps": 2, "logits_bit_exact_vs_tree_oracle": True,
+        "attention_last_layer_bit_exact_vs_tree": bool(np.array_equal(got, tree)),
+        "attention_last_layer_rel_vs_reference_order": rel, "bar": max(2e-6, 2e-9 * (T + 2))})
+    assert np.array_equal(got, tree)
+    assert rel <= max(2e-6, 2e-9 * (T + 2))
+    hip.q3_model_close(mg); host.q3_model_close(mo)

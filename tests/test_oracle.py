@@ -189,3 +189,38 @@ def test_sampler_restatement_equals_reference_sample(orc, vocab):
                 assert np.array_equal(a, b, equal_nan=True)
                 assert s.contents.seed == state.value
             ref.sampler_free(s)
+
+
+def test_kv_fill_twin_follows_the_documented_generator():
+    """orc_kv_fill_random (the oracle's twin of the product's q3_kv_fill_random, used by the long-context
+    parity tests) against a numpy restatement of the same splitmix64 recipe, in the reference's cache layout
+    [layer][seq_len][n_kv][head_dim] (src/model.c:360-361); rows beyond T stay untouched."""
+    host, orc = Q.host_lib(), Q.oracle_lib()
+    path = os.path.join(Q.tmp_dir(), "small.bin")
+    Q.synth("small", path)
+    m = host.q3_model_open(path.encode(), 0, 1)
+    p = m.contents.params
+    T, seed = 37, 99
+    kvd = p.n_kv_heads * p.head_dim
+    n = p.n_layers * p.seq_len * kvd
+    kc = np.ctypeslib.as_array(m.contents.state.k_cache, (n,)).reshape(p.n_layers, p.seq_len, p.n_kv_heads, p.head_dim)
+    vc = np.ctypeslib.as_array(m.contents.state.v_cache, (n,)).reshape(p.n_layers, p.seq_len, p.n_kv_heads, p.head_dim)
+    orc.orc_kv_fill_random(m, T, seed)
+
+    def gen(sd):
+        with np.errstate(over="ignore"):
+            i = np.arange(T * p.head_dim, dtype=np.uint64)
+            z = np.uint64(sd) + i * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z ^= z >> np.uint64(31)
+        u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        return ((u - np.float32(0.5)) * np.float32(2.0)).reshape(T, p.head_dim)
+
+    for l in range(p.n_layers):
+        for g in range(p.n_kv_heads):
+            assert np.array_equal(kc[l, :T, g, :], gen(seed + 2 * (l * 64 + g)))
+            assert np.array_equal(vc[l, :T, g, :], gen(seed + 2 * (l * 64 + g) + 1))
+    assert not kc[:, T:].any() and not vc[:, T:].any()
+    assert np.abs(kc[:, :T]).max() <= 1.0 and abs(float(kc[:, :T].mean())) < 0.05
+    host.q3_model_close(m)
