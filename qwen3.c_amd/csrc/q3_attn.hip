@@ -23,6 +23,7 @@
 
 #include "q3_device.hpp"
 #include "q3_kernels.hpp"
+#include "q3_tile.hpp"
 
 namespace q3k {
 
@@ -30,7 +31,7 @@ namespace q3k {
 
 #ifdef Q3_ATTN_STAMPS
 // every workgroup of grid layer 0 leaves eight device-clock marks: stamps[8 * workgroup + i]
-#define STAMP(i) do { if (a.stamps && blockIdx.z == 0 && threadIdx.x == 0) a.stamps[8 * (blockIdx.y * gridDim.x + blockIdx.x) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP(i) do { if (a.stamps && blockIdx.z == 0 && threadIdx.x == 0) a.stamps[8 * (slot * a.n_kv + g) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
@@ -51,6 +52,29 @@ __device__ __forceinline__ float2 ld_sc1_f2(const float* p) {
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
 
+// Final outputs of the stage (four codes per lane, one scale per 16 lanes): plain stores, or -- when workgroups of
+// the SAME launch consume them (k_attn_wo) -- ONE naturally aligned 8-byte {tag, value} store each (Guideline 16, R2:
+// the data is the flag; written through, sc1), which the consumers poll directly.
+template <bool PUB>
+__device__ __forceinline__ void out_codes(const Attn& a, unsigned tag, size_t elem, int packed) {
+    if (PUB) {
+        __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(a.og + (elem >> 2)),
+                           ((unsigned long long)tag << 32) | (unsigned)packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        reinterpret_cast<int*>(a.oq)[elem >> 2] = packed;
+    }
+}
+template <bool PUB>
+__device__ __forceinline__ void out_scale(const Attn& a, unsigned tag, size_t elem, float scale) {
+    if (PUB) {
+        const size_t P4 = (size_t)a.n_heads * a.hd / 4;
+        __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(a.og + P4 + (elem >> 6)),
+                           ((unsigned long long)tag << 32) | __float_as_uint(scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        a.os[elem >> 6] = scale;
+    }
+}
+
 // Merge of the chunk partials of one head (q3_numerics.h "attention", last three lines) +
 // q8_quantize, by ONE wave.  The sums over chunks are sequential by contract, but nothing
 // forces the LOADS to be: the (m_c, l_c) pairs are fetched 64 chunks at a time (one per lane)
@@ -68,8 +92,8 @@ __device__ __forceinline__ float4 ld_partial_row(const float* base, int c, int l
     return o;
 }
 
-template <int HD>
-__device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks, int lane) {
+template <int HD, bool PUB = false>
+__device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks, int lane, unsigned tag = 0) {
     constexpr int L4 = HD / 4;
     constexpr int ST = HD + 2;
     constexpr int AH = 16;                // O_c rows per burst = every chunk the in-launch merge ever sees (Q3_ATT_LONG / 64)
@@ -129,35 +153,27 @@ __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks
     float scale;
     const int packed = quantize_group16(y, scale);
     if (lane < L4) {
-        reinterpret_cast<int*>(a.oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
-        if ((lane & 15) == 0) a.os[((size_t)h * HD + 4 * lane) >> 6] = scale;
+        out_codes<PUB>(a, tag, (size_t)h * HD + 4 * lane, packed);
+        if ((lane & 15) == 0) out_scale<PUB>(a, tag, (size_t)h * HD + 4 * lane, scale);
         if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
     }
 }
 
-// HPW = query heads a wave may own (1 when the group has at most 4 query heads)
-template <int HD, int HPW>
-__global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
-    Attn a = a_in;
-    {   // batched prompt ingestion: position blockIdx.z of the launch (all strides 0 for a decode step)
-        const int z = blockIdx.z;
-        a.ctl += z;
-        a.qkv += (size_t)z * a.zs_qkv;
-        a.cs += (size_t)z * a.zs_cs;
-        a.oq += (size_t)z * a.zs_oq;
-        a.os += (size_t)z * a.zs_os;
-        a.part += (size_t)z * a.zs_part;
-        a.tickets += (size_t)z * a.zs_tickets;
-        if (a.of) a.of += (size_t)z * a.zs_of;
-    }
+// The attention stage as seen by ONE workgroup: kv head g, chunk slot `slot` of `nslots`.  Returns true
+// (workgroup-uniform) when THIS workgroup wrote the final outputs (codes + scales) of its kv head's query
+// heads: always in ATT_SINGLE, for the drawer of the last ticket in ATT_MERGE, never in ATT_LONG.
+// `rows_cap` (a multiple of 8, wave-uniform): rows of the first K/V tile that can hold cached positions --
+// the host knows pos < rows_cap when it picks the launch, so the rows beyond are not even requested
+// (they used to be pulled, 64 KB per workgroup whatever pos was, through one CU that takes in ~24 KB/us).
+// HPW = query heads a wave may own (1 when the group has at most 4 query heads); PUB: see out_codes.
+template <int HD, int HPW, bool PUB>
+__device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int slot, int nslots, int rows_cap,
+                                          float* Ks, float* Vs, int* last_flag_p) {
     constexpr int L4 = HD / 4;               // lanes holding one head as float4
     constexpr int CH = Q3_ATT_CHUNK;
     constexpr int NLD = CH * L4 / 256;       // float4 loads per thread per tile
-    __shared__ __attribute__((aligned(16))) float Ks[CH * HD];
-    __shared__ __attribute__((aligned(16))) float Vs[CH * HD];
-    __shared__ int last_flag;
-
-    const int g = blockIdx.x;
+    constexpr int RPL = 256 / L4;            // tile rows one load round of the workgroup covers
+    int& last_flag = *last_flag_p;
     const int kv_mul = a.n_heads / a.n_kv;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int half = lane >> 5, l = lane & 31;
@@ -172,12 +188,13 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
     // the K tile (32 KB at head_dim 128), which lands while the head norms run, and after the
     // norms the V tile, which streams in while the scores and the softmax are being computed.
     const int pos = a.ctl->pos;
+    const unsigned tag = PUB ? ((*a.epoch << 8) | a.layer_tag) : 0u;
     float4 kt[NLD], vt[NLD];
     // Slot 0 always has work (chunk 0), so it requests its tile before `pos` has even arrived;
     // the other slots first learn whether their chunk exists -- a speculative 64 KB per idle
     // workgroup would cost tens of MB of useless HBM reads per layer at short contexts.
-    if (blockIdx.y != 0 && (int)blockIdx.y * CH > pos) return;
-    const int tfirst = (int)blockIdx.y * CH;    // rows beyond pos are loaded but never used
+    if (slot != 0 && slot * CH > pos) return false;
+    const int tfirst = slot * CH;    // rows beyond pos are loaded but never used
     // At head_dim 128 a head is 32 lanes of float4, so ONE norm + rope pass serves two heads:
     // k of this step in the lower half of the wave, the wave's (first) query head in the upper
     // half (bfly32 inside a half adds exactly what bfly64 adds when the other half is zero).
@@ -216,15 +233,16 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
     for (int k = 0; k < NLD; k++) {
         const int idx = tid + k * 256;
         const int t = idx / L4, l4 = idx - t * L4;
-        kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
+        kt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k * RPL < rows_cap) kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
     }
     __builtin_amdgcn_sched_barrier(0);
 
     const int T = pos + 1;
     const int nchunks = (T + CH - 1) / CH;
-    if ((int)blockIdx.y >= nchunks) return;
+    if (slot >= nchunks) return false;
     STAMP(1);
-    const bool owner = ((nchunks - 1) % (int)gridDim.y) == (int)blockIdx.y;
+    const bool owner = ((nchunks - 1) % nslots) == slot;
 
     // k of this step (every wave redundantly, no barrier) and q of this wave's head(s):
     // norm + rope; kcur_m / vraw_m / q4 end up as slice (tid % L4) in every lane
@@ -276,7 +294,8 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
     for (int k = 0; k < NLD; k++) {
         const int idx = tid + k * 256;
         const int t = idx / L4, l4 = idx - t * L4;
-        vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
+        vt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k * RPL < rows_cap) vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
     }
     __builtin_amdgcn_sched_barrier(0);
     // wave 0 of the owning workgroup appends k and v of this step to the cache
@@ -284,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
         *reinterpret_cast<float4*>(a.kc + cbase + (size_t)pos * HD + 4 * lane) = kcur_m;
         *reinterpret_cast<float4*>(a.vc + cbase + (size_t)pos * HD + 4 * lane) = vraw_m;
     }
-    if (a.qdbg && blockIdx.y == 0 && lane < L4) {
+    if (a.qdbg && slot == 0 && lane < L4) {
 #pragma unroll
         for (int hi = 0; hi < HPW; hi++)
             if (wave + 4 * hi < kv_mul) *reinterpret_cast<float4*>(a.qdbg + (size_t)(g * kv_mul + wave + 4 * hi) * HD + 4 * lane) = q4[hi];
@@ -293,10 +312,10 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
     STAMP(2);
     const float root = sqrtf((float)HD);
     bool first = true;
-    for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
+    for (int c = slot; c < nchunks; c += nslots) {
         const int t0 = c * CH;
         const int Tc = (T - t0 < CH) ? T - t0 : CH;      // valid positions in this chunk
-        if (!first) {      // contexts beyond gridDim.y chunks only: the previous chunk's PV is over for this wave
+        if (!first) {      // contexts beyond nslots chunks only: the previous chunk's PV is over for this wave
             // (unconditional loads -- predicated accesses would push kt / vt out of registers -- with the
             // row clamped to the last valid one, so a short last chunk re-reads one row instead of
             // pulling 64 KB of unused cache)
@@ -461,8 +480,8 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
                     float scale;
                     const int packed = quantize_group16(y, scale);
                     if (lane < L4) {
-                        reinterpret_cast<int*>(a.oq)[((size_t)h * HD + 4 * lane) >> 2] = packed;
-                        if ((lane & 15) == 0) a.os[((size_t)h * HD + 4 * lane) >> 6] = scale;
+                        out_codes<PUB>(a, tag, (size_t)h * HD + 4 * lane, packed);
+                        if ((lane & 15) == 0) out_scale<PUB>(a, tag, (size_t)h * HD + 4 * lane, scale);
                         if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
                     }
                 }
@@ -481,11 +500,185 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi) {
             }
             __syncthreads();
             if (last_flag) {
-                for (int i = wave; i < kv_mul; i += 4) merge_partials<HD>(a, g * kv_mul + i, nchunks, lane);
+                for (int i = wave; i < kv_mul; i += 4) merge_partials<HD, PUB>(a, g * kv_mul + i, nchunks, lane, tag);
             }
         }
     }
     STAMP(7);
+    return multi == ATT_SINGLE || (multi == ATT_MERGE && last_flag != 0);
+}
+
+template <int HD, int HPW>
+__global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi, int rows_cap) {
+    Attn a = a_in;
+    {   // batched prompt ingestion: position blockIdx.z of the launch (all strides 0 for a decode step)
+        const int z = blockIdx.z;
+        a.ctl += z;
+        a.qkv += (size_t)z * a.zs_qkv;
+        a.cs += (size_t)z * a.zs_cs;
+        a.oq += (size_t)z * a.zs_oq;
+        a.os += (size_t)z * a.zs_os;
+        a.part += (size_t)z * a.zs_part;
+        a.tickets += (size_t)z * a.zs_tickets;
+        if (a.of) a.of += (size_t)z * a.zs_of;
+    }
+    __shared__ __attribute__((aligned(16))) float Ks[Q3_ATT_CHUNK * HD];
+    __shared__ __attribute__((aligned(16))) float Vs[Q3_ATT_CHUNK * HD];
+    __shared__ int last_flag;
+    (void)attn_body<HD, HPW, false>(a, multi, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, rows_cap, Ks, Vs, &last_flag);
+}
+
+
+// ---- attention + Wo in ONE launch (decode step, fewer than Q3_ATT_LONG cached positions) -----------
+// While the few attention workgroups walk their latency-bound chain (position -> head norms -> K tile ->
+// scores -> softmax -> V tile -> PV -> quantise: ~6 us during which HBM idles), the rest of the chip
+//   (1) pulls the Wo matrix into REGISTERS (d/(256 - n_att) rows per workgroup: 47.9 KB per CU at Qwen3-4B), and
+//   (2) waits, parked, for the attention output (P codes + P/64 scales, 4.3 KB): the finalising attention waves
+//       store it as 8-byte {tag, value} granules, written through (Guideline 16 R2: the data is the flag -- no drain,
+//       no counter, no second trip for the payload); every consumer wave re-reads its own granules until their tags
+//       carry this step and layer, parks the values in LDS, the workgroup meets once, and ~1 us of dot products +
+//       the residual add finish the stage -- instead of a kernel boundary plus a 4.7-us Wo launch.
+// Arithmetic: the attention body is k_attn's, the Wo rows go through tile_dot (q3_tile.hpp) as in the GEMV
+// launches, so the step stays bit-identical to the unfused path (tested both ways).
+// Grid: [n_att attention workgroups][256 - n_att consumer workgroups], 256 threads each = one workgroup per CU,
+// every one resident, attention first in dispatch order, and every wait is bounded: a consumer
+// that gives up raises *err (host-visible) and the host stops with a message.
+
+#ifndef Q3_SPIN_LIMIT
+#define Q3_SPIN_LIMIT (1u << 21)     // polls of >= 0.3 us each: a second or more before giving up
+#endif
+
+// The attention chain does all its memory round trips in its first ~3.5 us (position, q/k/v, K tile, V tile); weight
+// traffic from the rest of the chip during that time raises their latency (profiles/r03_l2_warm_experiment.md: +1.3 us
+// on the stage for 11 MB).  So the consumer workgroups sit out `ticks` x 10 ns of the device clock before they
+// request their Wo rows; the rows are still in registers ~1.5 us before the attention output appears.
+__device__ __forceinline__ void hold_back(int ticks) {
+    if (ticks <= 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+#ifdef Q3_ATTN_STAMPS
+// consumer workgroup wb leaves its marks behind the attention workgroups': stamps[8 * (n_att + wb) + i]
+#define WSTAMP(i) do { if (w.stamps && threadIdx.x == 0) w.stamps[8 * (blockIdx.x) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#endif
+template <int NJ, int RW>
+__device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, float* ls, int* flag) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    WSTAMP(0);
+    const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = w.n;
+    // rows of this wave: wb*rpw + uwave*RW + r while uwave*RW + r < rpw; the others are aimed past the matrix
+    // (rows >= d read as zero through the descriptor and move no bytes)
+    int rows[RW];
+    float res[RW];
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+        const int local = uwave * RW + r;
+        const int row = wb * w.rpw + local;
+        rows[r] = (local < w.rpw && row < w.d) ? row : w.d;
+        res[r] = rows[r] < w.d ? w.x[rows[r]] : 0.0f;
+    }
+    if (tid == 0) *flag = 1;                   // cleared by a wave whose bounded wait gives up
+    __syncthreads();
+    const WView wv = make_wview(w.W, w.S, w.d, n);
+    const TileLane tl = tile_lane<NJ>(wv, lane);
+    Tile<RW, NJ> T;
+    hold_back(w.delay);
+    WSTAMP(1);
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) tile_issue_one<RW, NJ>(T, wv, tl, rows[r] - r, r, j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WSTAMP(2);
+    // ---- the attention output arrives as {tag, value} granules: granule i < n/4 = dword i of the codes, n/4 + g =
+    // scale g.  Thread t owns code granules t, t + 256, ... and (t < n/64) one scale granule.  A wave first re-reads
+    // only its lanes' FIRST granule (a few lines per poll, so that 256 waiting workgroups do not load the fabric the
+    // attention chain's own round trips go through), then sweeps the rest until every tag matches.  Bounded.
+    constexpr int NG = NJ;                       // code granules per thread: (n/4) / 256 <= NJ
+    const unsigned tag = (*w.epoch << 8) | w.layer_tag;
+    const int ncode = n >> 2, nscale = n >> 6;
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    const g_u64* gr = (const g_u64*)w.gran;
+    unsigned val[NG];
+    unsigned sval = 0;
+    int ok = 1;
+    {
+        unsigned spins = 0;
+        for (;;) {
+            bool hit = true;
+            if (tid < ncode) {
+                const unsigned long long x = __hip_atomic_load(gr + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                val[0] = (unsigned)x;
+                hit = (unsigned)(x >> 32) == tag;
+            }
+            if (__all(hit)) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > Q3_SPIN_LIMIT) { ok = 0; break; }
+        }
+        WSTAMP(3);
+        while (ok) {
+            bool hit = true;
+#pragma unroll
+            for (int k = 1; k < NG; k++) {
+                const int i = tid + 256 * k;
+                if (i < ncode) {
+                    const unsigned long long x = __hip_atomic_load(gr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    val[k] = (unsigned)x;
+                    hit = hit && (unsigned)(x >> 32) == tag;
+                }
+            }
+            if (tid < nscale) {
+                const unsigned long long x = __hip_atomic_load(gr + ncode + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sval = (unsigned)x;
+                hit = hit && (unsigned)(x >> 32) == tag;
+            }
+            if (__all(hit)) break;
+            if (++spins > Q3_SPIN_LIMIT) { ok = 0; break; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const int i = tid + 256 * k;
+        if (i < ncode) reinterpret_cast<unsigned*>(lq)[i] = val[k];
+    }
+    if (tid < nscale) ls[tid] = __uint_as_float(sval);
+    if (!ok && lane == 0) {
+        *flag = 0;
+        __hip_atomic_store(w.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    WSTAMP(4);
+    __syncthreads();
+    WSTAMP(5);
+    ok = *flag;
+    float acc[RW];
+    tile_dot<RW, NJ>(T, n, lane, lq, ls, acc);
+    if (lane == 0 && ok) {
+#pragma unroll
+        for (int r = 0; r < RW; r++) {
+            if (rows[r] < w.d) w.x[rows[r]] = res[r] + acc[r];      // forward.c:295-298
+        }
+    }
+    WSTAMP(6);
+}
+
+template <int HD, int HPW, int NJ, int RW>
+__global__ __launch_bounds__(256, 2) void k_attn_wo(Attn a, int multi, int rows_cap, int nslots, WoView w) {
+    __shared__ __attribute__((aligned(16))) float Ks[Q3_ATT_CHUNK * HD];
+    __shared__ __attribute__((aligned(16))) float Vs[Q3_ATT_CHUNK * HD];
+    __shared__ int last_flag;
+    const int n_att = a.n_kv * nslots;
+    const int b = blockIdx.x;
+    if (b < n_att) {
+        const bool fin = attn_body<HD, HPW, true>(a, multi, b % a.n_kv, b / a.n_kv, nslots, rows_cap, Ks, Vs, &last_flag);
+        (void)fin;      // its granules are the publication: nothing to drain, no flag to raise
+        return;
+    }
+    wo_role<NJ, RW>(w, b - n_att, reinterpret_cast<int8_t*>(Ks), Vs, &last_flag);
 }
 
 // ---- batched prompt ingestion: zb consecutive positions share ONE staged K/V tile --------------
@@ -848,7 +1041,63 @@ void kv_append(const Attn& a, int ntok, hipStream_t st) {
     else hipLaunchKernelGGL(k_kv_append<64>, dim3(a.n_kv, ntok), dim3(64), 0, st, a);
 }
 
-void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st) {
+// Geometry of the launch: the attention workgroups and the extra ones together are ONE workgroup per CU (256) --
+// an extra workgroup that shares a CU with an attention workgroup puts its tens of KB of weight requests into the
+// queue the attention chain's dependent loads wait in (measured: +1.7 us on the stage).  So nwo = 256 - n_att extra
+// workgroups; fused, they split the d rows of Wo: rows per workgroup, wave-loads per row, rows per wave.
+// false = shape not covered (callers then launch attn() and the Wo GEMV separately).
+static int extra_workgroups(int n_att) { return n_att < 192 ? 256 - n_att : 64; }
+static bool wo_geometry(const WoView& w, int n_att, int* rpw, int* nj, int* rw) {
+    if (w.n % 64 || w.n > 4096 || w.d < 1) return false;
+    const int nwo = extra_workgroups(n_att);
+    *rpw = (w.d + nwo - 1) / nwo;
+    *nj = (w.n + 1023) / 1024;
+    *rw = (*rpw + 3) / 4;
+    return (*nj == 1 || *nj == 2 || *nj == 4) && *rw <= 5 && *rw * *nj <= 20;
+}
+static int attn_slots(int chunk_slots, AttMode mode) {
+    // ATT_MERGE serves positions below Q3_ATT_LONG only: never more than Q3_ATT_LONG / 64 chunks, so the
+    // launch need not dispatch (and retire) workgroups for slots that can have no chunk
+    const int merge_slots = chunk_slots < Q3_ATT_LONG / Q3_ATT_CHUNK ? chunk_slots : Q3_ATT_LONG / Q3_ATT_CHUNK;
+    return mode == ATT_SINGLE ? 1 : (mode == ATT_MERGE ? merge_slots : chunk_slots);
+}
+bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode) {
+    int rpw, nj, rw;
+    if (mode == ATT_LONG) return false;
+    if (!(a.nz <= 1 && !a.of && !a.prepared && a.n_heads / a.n_kv <= Q3_MAXG && (a.hd == 128 || a.hd == 64))) return false;
+    if (!w.W || !a.og || !a.epoch) return false;
+    return w.n == a.n_heads * a.hd && wo_geometry(w, a.n_kv * attn_slots(chunk_slots, mode), &rpw, &nj, &rw);
+}
+
+template <int HD, int HPW>
+static void launch_attn_wo(const Attn& a, AttMode mode, int rows_cap, int slots, WoView w, hipStream_t st) {
+    int rpw = 1, nj = 1, rw = 1;
+    const int n_att = a.n_kv * slots, nwo = extra_workgroups(n_att);
+    wo_geometry(w, n_att, &rpw, &nj, &rw);
+    w.rpw = rpw;
+    const dim3 grid(n_att + nwo), blk(256);
+#define Q3_AW(NJ, RW) hipLaunchKernelGGL((k_attn_wo<HD, HPW, NJ, RW>), grid, blk, 0, st, a, (int)mode, rows_cap, slots, w)
+    switch (nj * 8 + rw) {
+        case 1 * 8 + 1: Q3_AW(1, 1); break;
+        case 1 * 8 + 2: Q3_AW(1, 2); break;
+        case 1 * 8 + 3: Q3_AW(1, 3); break;
+        case 1 * 8 + 4: Q3_AW(1, 4); break;
+        case 2 * 8 + 1: Q3_AW(2, 1); break;
+        case 2 * 8 + 2: Q3_AW(2, 2); break;
+        case 2 * 8 + 3: Q3_AW(2, 3); break;
+        case 2 * 8 + 4: Q3_AW(2, 4); break;
+        case 4 * 8 + 1: Q3_AW(4, 1); break;
+        case 4 * 8 + 2: Q3_AW(4, 2); break;
+        case 4 * 8 + 3: Q3_AW(4, 3); break;
+        case 4 * 8 + 4: Q3_AW(4, 4); break;
+        case 1 * 8 + 5: Q3_AW(1, 5); break;
+        case 2 * 8 + 5: Q3_AW(2, 5); break;
+        default: Q3_AW(4, 5); break;
+    }
+#undef Q3_AW
+}
+
+void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows_cap, const WoView* wo) {
     if (a.n_heads / a.n_kv > Q3_MAXG) {
         fprintf(stderr, "[q3hip] attention: more than %d query heads per kv head\n", Q3_MAXG);
         exit(EXIT_FAILURE);
@@ -857,12 +1106,21 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st) {
         fprintf(stderr, "[q3hip] attention: head_dim %d not supported (64 or 128)\n", a.hd);
         exit(EXIT_FAILURE);
     }
+    if (rows_cap < 8 || rows_cap > Q3_ATT_CHUNK) rows_cap = Q3_ATT_CHUNK;
     const int nz = a.nz > 1 ? a.nz : 1;
     const bool two = a.n_heads / a.n_kv > 4;
-    // ATT_MERGE serves positions below Q3_ATT_LONG only: never more than Q3_ATT_LONG / 64 chunks, so the
-    // launch need not dispatch (and retire) workgroups for slots that can have no chunk
-    const int merge_slots = chunk_slots < Q3_ATT_LONG / Q3_ATT_CHUNK ? chunk_slots : Q3_ATT_LONG / Q3_ATT_CHUNK;
-    const int slots = mode == ATT_SINGLE ? 1 : (mode == ATT_MERGE ? merge_slots : chunk_slots);
+    const int slots = attn_slots(chunk_slots, mode);
+    if (wo) {
+        if (!attn_wo_supported(a, *wo, chunk_slots, mode)) {
+            fprintf(stderr, "[q3hip] attention: fused Wo launch requested for a shape it does not cover\n");
+            exit(EXIT_FAILURE);
+        }
+        if (a.hd == 128 && !two) launch_attn_wo<128, 1>(a, mode, rows_cap, slots, *wo, st);
+        else if (a.hd == 128) launch_attn_wo<128, 2>(a, mode, rows_cap, slots, *wo, st);
+        else if (!two) launch_attn_wo<64, 1>(a, mode, rows_cap, slots, *wo, st);
+        else launch_attn_wo<64, 2>(a, mode, rows_cap, slots, *wo, st);
+        return;
+    }
     if (nz > 1) {
         // a pass of the batched prompt path: blocks of positions share a staged tile; as many positions
         // per block as still leaves ~2 workgroups per CU
@@ -884,10 +1142,10 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st) {
         return;
     }
     dim3 grid(a.n_kv, slots, nz);
-    if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn<128, 1>), grid, dim3(256), 0, st, a, (int)mode);
-    else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, (int)mode);
-    else if (!two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, (int)mode);
-    else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a, (int)mode);
+    if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn<128, 1>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
+    else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
+    else if (!two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
+    else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
     if (mode == ATT_LONG) {
         if (a.hd == 128) hipLaunchKernelGGL(k_attn_merge<128>, dim3(a.n_heads * 2, nz), dim3(64), 0, st, a);
         else hipLaunchKernelGGL(k_attn_merge<64>, dim3(a.n_heads, nz), dim3(64), 0, st, a);
@@ -898,10 +1156,14 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st) {
 // (cos,sin) row of `pos` copied to a fixed address so that no later load depends on pos
 __global__ __launch_bounds__(256) void k_begin(const Ctl* ctl, const int8_t* __restrict__ eq,
                                                const float* __restrict__ es, int dim, float* __restrict__ x,
-                                               const float* __restrict__ rope, int hd, float* __restrict__ cs) {
+                                               const float* __restrict__ rope, int hd, float* __restrict__ cs,
+                                               unsigned* __restrict__ epoch) {
     const int pos = ctl->pos;
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < hd; i += 256) cs[i] = rope[(size_t)pos * hd + i];
+        // the step counter that tags this step's in-launch hand-offs (k_attn_wo): a granule left by an earlier step,
+        // or by one that was cut short, can never carry it
+        if (epoch && threadIdx.x == 0) epoch[0] = epoch[0] + 1u;
     }
     if (eq) {
         // x = q*s of one embedding row (reference model.c:201-206 dequantises the whole table
@@ -913,9 +1175,9 @@ __global__ __launch_bounds__(256) void k_begin(const Ctl* ctl, const int8_t* __r
     }
 }
 void begin_step(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, const float* rope,
-                int hd, float* cs, hipStream_t st) {
+                int hd, float* cs, hipStream_t st, unsigned* epoch) {
     const int blocks = eq ? (dim + 255) / 256 : 1;
-    hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(256), 0, st, ctl, eq, es, dim, x, rope, hd, cs);
+    hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(256), 0, st, ctl, eq, es, dim, x, rope, hd, cs, epoch);
 }
 
 

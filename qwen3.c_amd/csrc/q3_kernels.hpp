@@ -60,6 +60,13 @@ struct Attn {
     int nz;              // 0 or 1 = a single position
     int zs_qkv, zs_cs, zs_oq, zs_os, zs_tickets, zs_of;
     size_t zs_part;
+    // k_attn_wo only: the outputs leave as 8-byte {tag, value} granules for the consumer workgroups of the same
+    // launch -- granule i < P/4 carries dword i of the codes, granule P/4 + g the scale of group g; tag =
+    // (*epoch << 8) | layer_tag, *epoch being the step counter k_begin advances (so a granule of an earlier step or
+    // of another layer never matches)
+    unsigned long long* og;
+    const unsigned* epoch;
+    unsigned layer_tag;
 };
 // k (head norm + RoPE) and v of `ntok` consecutive positions into the cache (reference forward.c:270-286),
 // ahead of a batched attn(): qkv rows of stride zs_qkv, (cos,sin) rows of stride hd, positions from ctl[t].pos
@@ -75,13 +82,37 @@ void kv_append(const Attn& a, int ntok, hipStream_t st);
 enum AttMode { ATT_SINGLE = 0, ATT_MERGE = 1, ATT_LONG = 2 };
 #define Q3_ATT_LONG 1024
 inline AttMode attn_mode(int pos) { return pos < 64 ? ATT_SINGLE : (pos < Q3_ATT_LONG ? ATT_MERGE : ATT_LONG); }
-void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st);
+// A step's launches are captured once per SHAPE: ATT_SINGLE comes in four, by the rows of the one K/V tile
+// that can hold cached positions (pos < 16, 32, 48, 64 -> rows_cap 16, 32, 48, 64: the rest is not requested).
+#define Q3_STEP_SHAPES 6
+inline int step_shape(int pos) { return pos < 64 ? pos / 16 : (pos < Q3_ATT_LONG ? 4 : 5); }
+inline int step_rows_cap(int pos) { return pos < 64 ? (pos / 16 + 1) * 16 : 64; }
+
+// The Wo GEMV + residual add behind the attention, in the SAME launch (k_attn_wo in q3_attn.hip; reference
+// forward.c:291-298).
+struct WoView {
+    const int8_t* W;      // [d][n] codes
+    const float* S;       // [d][n/64] scales
+    int n, d, rpw;        // rows per consumer workgroup
+    float* x;             // x[d] += W . att
+    const unsigned long long* gran;   // the attention output as {tag, value} granules (Attn::og of the same launch)
+    const unsigned* epoch;            // step counter (k_begin)
+    unsigned layer_tag;               // low byte of the tag
+    unsigned* err;        // host-mapped word, set to 1 when a bounded wait gives up
+    unsigned long long* stamps;   // diagnostic builds only (-DQ3_ATTN_STAMPS): eight device-clock marks per consumer workgroup
+    int delay;            // device-clock ticks (10 ns) the extra workgroups hold their weight requests back after entry
+};
+// rows per consumer workgroup / whether the fused launch covers this shape (else: attn() then gemv())
+bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode);
+// `rows_cap`: see step_rows_cap (64 = whole tile).  `wo` non-null: the fused launch (ATT_SINGLE / ATT_MERGE only).
+void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows_cap = 64, const WoView* wo = nullptr);
 
 void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, hipStream_t st);
 // first kernel of a step: x = embedding row of ctl->token (eq may be null on later pipeline
 // stages) and cs = rope[ctl->pos]
 void begin_step(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, const float* rope,
-                int hd, float* cs, hipStream_t st);
+                int hd, float* cs, hipStream_t st, unsigned* epoch = nullptr);
+
 // scratch: 256 words of device memory
 void argmax(const float* logits, int n, float* scratch, int* out, int* out2, hipStream_t st);
 void set_ctl(Ctl* ctl, const int* tok_src, int tok_imm, int pos, hipStream_t st);

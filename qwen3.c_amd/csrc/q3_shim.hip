@@ -125,16 +125,21 @@ struct Dev {
     int* amax = nullptr;
     float* amax_scratch = nullptr;
     unsigned* tickets = nullptr;  // attention chunk tickets, [KV], zero between launches
+    unsigned* epoch = nullptr;    // step counter advanced by k_begin: tags the in-launch hand-offs of k_attn_wo
+    unsigned long long* att_g = nullptr;   // attention output as {tag, value} granules [P/4 + P/64] (fused launch)
+    unsigned* err_host = nullptr; // host-mapped: [0] set by a consumer whose bounded wait gave up
+    bool fuse = true;             // attention + Wo in one launch below Q3_ATT_LONG cached positions (Q3_FUSE=0: separate launches)
+    int pf_delay = 250;           // x 10 ns: how long the consumer workgroups of k_attn_wo hold their Wo requests back (Q3_WO_DELAY)
     unsigned long long* stamps = nullptr;
     int* amax_host = nullptr;
     int max_chunks = 1, chunk_slots = 1;
     bool logits_pinned = false;
     bool use_graph = true;
-    hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};   // one per attention launch shape (q3k::AttMode)
+    hipGraphExec_t gexec[Q3_STEP_SHAPES] = {};   // one per launch shape of a step (q3k::step_shape)
     // pipeline / on-device loop: one KV cache per concurrent token stream
     int n_streams = 1;
     size_t cache_floats = 0;      // floats of one stream's K (or V) cache of one layer
-    std::vector<hipGraphExec_t> pgexec;   // [stream*3 + AttMode], step without the ctl upload
+    std::vector<hipGraphExec_t> pgexec;   // [stream*Q3_STEP_SHAPES + shape], step without the ctl upload
     int* ptokens = nullptr;       // last stage: [n_streams][cap] chosen tokens
     // fp16 contrast path (BASELINE config 5): weights dequantised to binary16 at attach, activations fp32
     bool fp16 = false;
@@ -412,7 +417,19 @@ Dev* attach(Model* m, const AttachOpts& opt = AttachOpts()) {
     if (d->loopback) {
         for (int i = 0; i < 2; i++) d->outbox[i] = dalloc<float>(d, d->dim + 1);
     }
-    d->pgexec.assign((size_t)d->n_streams * 3, nullptr);
+    d->pgexec.assign((size_t)d->n_streams * Q3_STEP_SHAPES, nullptr);
+    d->epoch = dalloc<unsigned>(d, 4);
+    HIPCHK(hipMemsetAsync(d->epoch, 0, 4 * sizeof(unsigned), d->st));
+    d->att_g = dalloc<unsigned long long>(d, (size_t)d->P / 4 + d->P / 64);
+    HIPCHK(hipMemsetAsync(d->att_g, 0, ((size_t)d->P / 4 + d->P / 64) * 8, d->st));     // tag 0 = never a step's tag
+    HIPCHK(hipHostMalloc((void**)&d->err_host, 4 * sizeof(unsigned), hipHostMallocMapped));
+    memset(d->err_host, 0, 4 * sizeof(unsigned));
+    {
+        const char* ef = getenv("Q3_FUSE");
+        d->fuse = !(ef && ef[0] == '0');
+        const char* ed = getenv("Q3_WO_DELAY");
+        if (ed) d->pf_delay = atoi(ed);
+    }
     if (getenv("Q3_STAMPS")) { d->stamps = dalloc<unsigned long long>(d, 16384); HIPCHK(hipMemset(d->stamps, 0, 16384 * 8)); }
     HIPCHK(hipHostMalloc((void**)&d->ctl_host, sizeof(q3k::Ctl), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&d->amax_host, sizeof(int), hipHostMallocDefault));
@@ -462,6 +479,7 @@ void destroy_dev(Dev* d) {
     for (void* p : d->allocs) (void)hipFree(p);
     (void)hipHostFree(d->ctl_host);
     (void)hipHostFree(d->amax_host);
+    if (d->err_host) (void)hipHostFree(d->err_host);
     if (d->samp_tok_host) (void)hipHostFree(d->samp_tok_host);
     (void)hipStreamDestroy(d->st);
     delete d;
@@ -570,7 +588,21 @@ void enqueue_layer_f16(Dev* d, int l, q3k::AttMode mode, int stream) {
     q3k::gemv_f16(L.dn_h, d->hid, d->dim, d->h, nullptr, d->x, q3k::EPI_RESID, d->st);
 }
 
-void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
+// The Wo GEMV of layer l as the consumer half of k_attn_wo (fewer than Q3_ATT_LONG cached positions)
+q3k::WoView wo_view(Dev* d, int l) {
+    const LayerDev& L = d->layers[l];
+    q3k::WoView w;
+    memset(&w, 0, sizeof(w));
+    w.W = L.wo_q; w.S = L.wo_s; w.n = d->P; w.d = d->dim;
+    w.x = d->x;
+    w.gran = d->att_g; w.epoch = d->epoch; w.layer_tag = (unsigned)(l & 255) + 1u;
+    w.delay = d->pf_delay;
+    w.stamps = d->stamps;
+    HIPCHK(hipHostGetDevicePointer((void**)&w.err, d->err_host, 0));
+    return w;
+}
+
+void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0, int rows_cap = 64) {
     if (d->fp16) {
         enqueue_layer_f16(d, l, mode, stream);
         return;
@@ -590,10 +622,22 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
     }
     {   // head norms + RoPE + cache append + attention + quantise (forward.c:267-291)
         q3k::Attn a = attn_args(d, l, stream);
-        {
-            Timed t(d, "attn", 0.0);
-            q3k::attn(a, d->chunk_slots, mode, d->st);
+        bool fused = false;
+        if (d->fuse && mode != q3k::ATT_LONG) {
+            const q3k::WoView w = wo_view(d, l);
+            a.og = d->att_g; a.epoch = d->epoch; a.layer_tag = w.layer_tag;
+            if (q3k::attn_wo_supported(a, w, d->chunk_slots, mode)) {
+                // attention AND Wo + residual in one launch (forward.c:267-298)
+                Timed t(d, "attn_wo", q3_gemv_bytes(d->dim, d->P));
+                q3k::attn(a, d->chunk_slots, mode, d->st, rows_cap, &w);
+                fused = true;
+            }
         }
+        if (!fused) {
+            Timed t(d, "attn", 0.0);
+            q3k::attn(a, d->chunk_slots, mode, d->st, rows_cap);
+        }
+        if (fused) goto after_wo;
     }
     {   // Wo + residual (forward.c:292-298)
         g.W = L.wo_q; g.S = L.wo_s; g.n = d->P; g.d = d->dim;
@@ -603,6 +647,7 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0) {
         g.stamps = stamp_for("wo");
         q3k::gemv(g, q3k::PRO_Q8, q3k::EPI_RESID, d->st);
     }
+after_wo:
     {   // rmsnorm + quantise + gate/up + SwiGLU (forward.c:303-321)
         g.W = L.gu_q; g.S = L.gu_s; g.n = d->dim; g.d = 2 * d->hid;
         g.xf = d->x; g.nw = L.ffn_nw; g.out = d->h;
@@ -640,28 +685,36 @@ void enqueue_head(Dev* d) {
 }
 
 // everything of one step that runs on this device, between the ctl upload and the logits
-void enqueue_step(Dev* d, q3k::AttMode mode, int stream = 0) {
+void enqueue_step(Dev* d, int pos_shape, int stream = 0) {
+    // pos_shape: any position of the launch shape the step is captured for (q3k::step_shape)
+    const q3k::AttMode mode = q3k::attn_mode(pos_shape);
+    const int rows_cap = q3k::step_rows_cap(pos_shape);
     {
         Timed t(d, "begin", 0.0);
         q3k::begin_step(d->ctl, (d->has_embed && !d->fp16) ? d->emb_q : nullptr, d->emb_s, d->dim, d->x, d->rope, d->hd,
-                        d->cs_cur, d->st);
+                        d->cs_cur, d->st, d->epoch);
         if (d->fp16 && d->has_embed) q3k::embed_half(d->ctl, d->emb_h, d->dim, d->x, d->st);
     }
-    for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, mode, stream);
+    for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, mode, stream, rows_cap);
     if (d->has_cls) enqueue_head(d);
 }
 
-void launch_stage(Dev* d, q3k::AttMode mode, int stream);
+void launch_stage(Dev* d, int pos, int stream);
+
+// a consumer of an in-launch hand-off that gave up waiting raises err_host[0]: stop loudly, the step's result is void
+void check_handoff(Dev* d) {
+    if (d->err_host && *(volatile unsigned*)d->err_host) Q3_DIE("an in-launch hand-off (attention -> Wo) timed out on the device");
+}
 
 void fetch_logits_async(Dev* d) {
     HIPCHK(hipMemcpyAsync(d->logits_host, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost, d->st));
 }
 
-hipGraphExec_t build_graph(Dev* d, q3k::AttMode mode, bool with_logits) {
+hipGraphExec_t build_graph(Dev* d, int pos, bool with_logits) {
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(d->st, hipStreamCaptureModeThreadLocal));
     HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
-    enqueue_step(d, mode);
+    enqueue_step(d, pos);
     if (with_logits) fetch_logits_async(d);
     HIPCHK(hipStreamEndCapture(d->st, &graph));
     hipGraphExec_t exec = nullptr;
@@ -700,7 +753,6 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
     check_step_args(d, token, pos);
     HIPCHK(hipSetDevice(d->device));
     if (d->world > 1) Q3_DIE("this Model is one stage of a %d-stage pipeline: use q3_pipeline_run()", d->world);
-    const q3k::AttMode mode = q3k::attn_mode(pos);
     if (!to_host) {
         // Asynchronous step (q3_forward_device): the caller may queue several of these without a sync, so
         // {token, pos} must not travel through the one pinned host slot a later call would overwrite before
@@ -708,7 +760,7 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
         // the graph WITHOUT the ctl upload and without the 608-KB logits download.
         prof_begin(d);
         q3k::set_ctl(d->ctl, nullptr, token, pos, d->st);
-        launch_stage(d, mode, 0);
+        launch_stage(d, pos, 0);
         if (d->tap) {
             HIPCHK(hipMemcpyAsync(d->tap_host.data(), d->tap_dev, d->tap_host.size() * 4, hipMemcpyDeviceToHost, d->st));
         }
@@ -719,15 +771,18 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
     d->ctl_host->pos = pos;
     const bool pinned_ok = d->logits_pinned;
     if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
-        hipGraphExec_t& ex = d->gexec[(int)mode];
-        if (!ex) ex = build_graph(d, mode, true);
+        hipGraphExec_t& ex = d->gexec[q3k::step_shape(pos)];
+        if (!ex) ex = build_graph(d, pos, true);
         HIPCHK(hipGraphLaunch(ex, d->st));
-        if (to_host) wait_step(d);
+        if (to_host) {
+            wait_step(d);
+            check_handoff(d);
+        }
         return;
     }
     prof_begin(d);
     HIPCHK(hipMemcpyAsync(d->ctl, d->ctl_host, sizeof(q3k::Ctl), hipMemcpyHostToDevice, d->st));
-    enqueue_step(d, mode);
+    enqueue_step(d, pos);
     if (d->tap) {
         HIPCHK(hipMemcpyAsync(d->tap_host.data(), d->tap_dev, d->tap_host.size() * 4, hipMemcpyDeviceToHost, d->st));
     }
@@ -741,6 +796,7 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
         }
     }
     prof_collect(d);
+    if (to_host) check_handoff(d);
 }
 
 // ---- context for the stand-alone ops ---------------------------------------
@@ -930,6 +986,7 @@ void q3_device_sync(Model* m) {
     Dev* d = lookup(m);
     if (d) {
         HIPCHK(hipStreamSynchronize(d->st));
+        check_handoff(d);
     }
 }
 
@@ -948,6 +1005,7 @@ void q3_forward_device(Model* m, int token, int pos) {
 void q3_logits_fetch(Model* m) {
     Dev* d = attach(m);
     HIPCHK(hipStreamSynchronize(d->st));
+    check_handoff(d);
     HIPCHK(hipMemcpy(m->state.logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost));
 }
 
@@ -987,21 +1045,21 @@ void ensure_token_log(Dev* d, int per_stream) {
 
 __global__ void k_log_token(const int* tok, int* log_slot) { *log_slot = *tok; }
 
-void launch_stage(Dev* d, q3k::AttMode mode, int stream) {
+void launch_stage(Dev* d, int pos, int stream) {
     const bool pinned_ok = true;
     if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
-        hipGraphExec_t& ex = d->pgexec[(size_t)stream * 3 + (int)mode];
+        hipGraphExec_t& ex = d->pgexec[(size_t)stream * Q3_STEP_SHAPES + q3k::step_shape(pos)];
         if (!ex) {
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(d->st, hipStreamCaptureModeThreadLocal));
-            enqueue_step(d, mode, stream);
+            enqueue_step(d, pos, stream);
             HIPCHK(hipStreamEndCapture(d->st, &graph));
             HIPCHK(hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0));
             HIPCHK(hipGraphDestroy(graph));
         }
         HIPCHK(hipGraphLaunch(ex, d->st));
     } else {
-        enqueue_step(d, mode, stream);
+        enqueue_step(d, pos, stream);
     }
 }
 
@@ -1043,7 +1101,7 @@ void pipeline_tick(Dev* d, int first_token, int pos0, int s, int k) {
     int* tok_slot_out = reinterpret_cast<int*>(d->xout + d->dim);
     HIPCHK(hipSetDevice(d->device));
     q3k::set_ctl(d->ctl, (r == 0 && k > 0) ? tok_slot_in : nullptr, r == 0 ? first_token : 0, pos, d->st);
-    launch_stage(d, q3k::attn_mode(pos), s);
+    launch_stage(d, pos, s);
     if (!last) {
         HIPCHK(hipMemcpyAsync(d->xout, d->x, (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
     } else {
@@ -1102,6 +1160,7 @@ int q3_pipeline_tokens(Model* m, int stream, int* out, int n) {
     if (!d->ptokens || stream < 0 || stream >= d->n_streams) return 0;
     if (n > d->ptokens_cap) n = d->ptokens_cap;
     HIPCHK(hipStreamSynchronize(d->st));
+    check_handoff(d);
     HIPCHK(hipMemcpy(out, d->ptokens + (size_t)stream * d->ptokens_cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     return n;
 }
@@ -1440,10 +1499,11 @@ void q3_layer_step(Model* m, int layer, int pos, const float* x_in, float* x_out
     if (layer < d->l0 || layer >= d->l1) Q3_DIE("layer %d is not on this device", layer);
     check_step_args(d, 0, pos);
     q3k::set_ctl(d->ctl, nullptr, 0, pos, d->st);
-    q3k::begin_step(d->ctl, nullptr, nullptr, d->dim, d->x, d->rope, d->hd, d->cs_cur, d->st);
+    q3k::begin_step(d->ctl, nullptr, nullptr, d->dim, d->x, d->rope, d->hd, d->cs_cur, d->st, d->epoch);
     HIPCHK(hipMemcpyAsync(d->x, x_in, (size_t)d->dim * 4, hipMemcpyHostToDevice, d->st));
-    enqueue_layer(d, layer, q3k::attn_mode(pos));
+    enqueue_layer(d, layer, q3k::attn_mode(pos), 0, q3k::step_rows_cap(pos));
     HIPCHK(hipStreamSynchronize(d->st));
+    check_handoff(d);
     HIPCHK(hipMemcpy(x_out, d->x, (size_t)d->dim * 4, hipMemcpyDeviceToHost));
     prof_collect(d);
 }

@@ -314,3 +314,29 @@ def test_decode_over_a_pseudo_random_cache_vs_oracle(hip, host, orc, name, T):
         assert np.array_equal(a, b), (name, T, k)
         tok = int(a.argmax())
     hip.q3_model_close(mg); host.q3_model_close(mo)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "4Bmini"])
+def test_fused_attention_wo_launch_equals_separate_launches(hip, name):
+    """k_attn_wo (attention + Wo in one launch, the attention output handed over as tagged granules) against the
+    attention launch followed by the Wo GEMV (Q3_FUSE=0, read at attach): logits bit-identical at every position
+    through the four one-chunk launch shapes (rows_cap 16/32/48/64) and into the in-launch-merge shape, and again
+    after a rewind of pos (same position twice in a row: the step counter, not the position, tags the hand-off)."""
+    path = os.path.join(Q.tmp_dir(), f"{name}.bin")
+    spec = Q.synth(name, path)
+    n = min(150, spec.seq_len - 2)
+    os.environ["Q3_FUSE"] = "0"
+    try:
+        ma = hip.q3_model_open(path.encode(), 0, 0)
+        assert hip.q3_device_attach(ma) == 0
+    finally:
+        del os.environ["Q3_FUSE"]
+    mb = hip.q3_model_open(path.encode(), 0, 0)
+    assert hip.q3_device_attach(mb) == 0
+    tok = 3
+    for pos in list(range(n)) + [7, 7, 70 if n > 71 else 5, 0]:
+        a = Q.logits_array(ma, hip.forward(ma, tok, pos)).copy()
+        b = Q.logits_array(mb, hip.forward(mb, tok, pos))
+        assert np.array_equal(a, b), (name, pos)
+        tok = int(a.argmax())
+    hip.q3_model_close(ma); hip.q3_model_close(mb)
