@@ -172,7 +172,6 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int s
     constexpr int L4 = HD / 4;               // lanes holding one head as float4
     constexpr int CH = Q3_ATT_CHUNK;
     constexpr int NLD = CH * L4 / 256;       // float4 loads per thread per tile
-    constexpr int RPL = 256 / L4;            // tile rows one load round of the workgroup covers
     int& last_flag = *last_flag_p;
     const int kv_mul = a.n_heads / a.n_kv;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -229,12 +228,15 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int s
     }
     if (!a.prepared) rope_slices<HD>(a.cs, FUSE ? l : lane, ca, cb);
     __builtin_amdgcn_sched_barrier(0);
+    // Branch-free (a branch between loads makes the compiler lose count of vmcnt, and the head norms below would
+    // wait for the whole tile): the tile is read through a buffer descriptor that ends after `rows_cap` rows, so
+    // the requests for rows beyond it return zeros and move no bytes.
+    const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(a.kc + cbase + (size_t)tfirst * HD, 0, rows_cap * HD * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(a.vc + cbase + (size_t)tfirst * HD, 0, rows_cap * HD * 4, 0x00020000);
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
-        const int idx = tid + k * 256;
-        const int t = idx / L4, l4 = idx - t * L4;
-        kt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k * RPL < rows_cap) kt[k] = *reinterpret_cast<const float4*>(a.kc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
+        const v4i r = __builtin_amdgcn_raw_buffer_load_b128(kres, (tid + k * 256) * 16, 0, 0);
+        kt[k] = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -292,10 +294,8 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int s
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
-        const int idx = tid + k * 256;
-        const int t = idx / L4, l4 = idx - t * L4;
-        vt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k * RPL < rows_cap) vt[k] = *reinterpret_cast<const float4*>(a.vc + cbase + (size_t)(tfirst + t) * HD + 4 * l4);
+        const v4i r = __builtin_amdgcn_raw_buffer_load_b128(vres, (tid + k * 256) * 16, 0, 0);
+        vt[k] = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
     }
     __builtin_amdgcn_sched_barrier(0);
     // wave 0 of the owning workgroup appends k and v of this step to the cache
@@ -929,21 +929,16 @@ __device__ __forceinline__ int q8_code1(float y, float scale, float inv) {
     if (__builtin_expect(gg > 0.499f || !(scale >= 1e-30f), 0)) return q8_code_exact(y, scale);
     return (int)copysignf(fminf(floorf(t), 127.0f), y);
 }
-template <int HD>
-__global__ __launch_bounds__(64) void k_attn_merge(Attn a_in) {
-    Attn a = a_in;
-    {
-        const int z = blockIdx.y;
-        a.ctl += z;
-        a.oq += (size_t)z * a.zs_oq;
-        a.os += (size_t)z * a.zs_os;
-        a.part += (size_t)z * a.zs_part;
-        if (a.of) a.of += (size_t)z * a.zs_of;
-    }
+// merge of one 64-value group (head h, group grp) by ONE wave; PUB: the codes and the scale leave as tagged granules
+#ifdef Q3_ATTN_STAMPS
+#define MSTAMP(i) do { if (PUB && a.stamps && lane == 0) a.stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MSTAMP(i) do {} while (0)
+#endif
+template <int HD, bool PUB>
+__device__ __forceinline__ void merge_group(const Attn& a, int h, int grp, int lane) {
     constexpr int ST = HD + 2;
-    constexpr int GPH = HD / 64;                // quantisation groups per head
-    const int h = blockIdx.x / GPH, grp = blockIdx.x % GPH;
-    const int lane = threadIdx.x;
+    MSTAMP(0);
     const float* base = a.part + (size_t)h * a.max_chunks * ST;
     const int d = grp * 64 + lane;
     // Everything the first 64 chunks need -- their (m_c, l_c) pairs, one per lane, and this lane's
@@ -956,8 +951,11 @@ __global__ __launch_bounds__(64) void k_attn_merge(Attn a_in) {
 #pragma unroll
     for (int k = 0; k < 64; k++) o0[k] = base[(size_t)(k < rmax ? k : rmax) * ST + d];
     const int nchunks = a.ctl->pos / Q3_ATT_CHUNK + 1;
+    unsigned tag = 0;
+    if (PUB) tag = (*a.epoch << 8) | a.layer_tag;
     if (lane >= nchunks) ml0 = make_float2(-3.0e38f, 0.0f);
     float M = wave_max(ml0.x);
+    MSTAMP(1);
     for (int c0 = 64; c0 < nchunks; c0 += 64) {
         const int c = c0 + lane;
         const float mc = c < nchunks ? base[(size_t)c * ST + HD] : -3.0e38f;
@@ -971,13 +969,19 @@ __global__ __launch_bounds__(64) void k_attn_merge(Attn a_in) {
             wl = wc * ml0.y;
         }
         const int cnt = nchunks < 64 ? nchunks : 64;
+        // the sums over chunks are sequential by contract; blocks of eight steps run without a branch per step (a
+        // branch per step cost the 64-chunk chain 1.5 us), the steps past the last chunk keep L and A by a select
 #pragma unroll
-        for (int k = 0; k < 64; k++) {
-            if (k < cnt) {
-                const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wc), k));
-                const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), k));
-                L = L + t;
-                A = A + w * o0[k];
+        for (int k0 = 0; k0 < 64; k0 += 8) {
+            if (k0 < cnt) {
+#pragma unroll
+                for (int k = k0; k < k0 + 8; k++) {
+                    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wc), k));
+                    const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), k));
+                    const float Ln = L + t, An = A + w * o0[k];
+                    L = k < cnt ? Ln : L;
+                    A = k < cnt ? An : A;
+                }
             }
         }
     }
@@ -1008,12 +1012,59 @@ __global__ __launch_bounds__(64) void k_attn_merge(Attn a_in) {
             }
         }
     }
+    MSTAMP(2);
     const float y = A / L;
     const float scale = q3_q8_scale(wave_max(fabsf(y)));
     const int q = q8_code1(y, scale, __builtin_amdgcn_rcpf(scale));
-    a.oq[(size_t)h * HD + d] = (int8_t)q;
-    if (lane == 0) a.os[((size_t)h * HD + d) >> 6] = scale;
+    if (PUB) {
+        // four lanes' codes -> one dword (little-endian, as the int8 array holds them), one granule per quad
+        const int b0 = q & 255;
+        const int b1 = lane_xor_i<1>(b0);                 // the other lane of the pair
+        const int pair = (lane & 1) ? ((b0 << 8) | b1) : ((b1 << 8) | b0);
+        const int other = lane_xor_i<2>(pair);            // the other pair of the quad
+        const int packed = (lane & 2) ? ((pair << 16) | other) : ((other << 16) | pair);
+        if ((lane & 3) == 0) out_codes<true>(a, tag, (size_t)h * HD + d, packed);
+        if (lane == 0) out_scale<true>(a, tag, (size_t)h * HD + d, scale);
+    } else {
+        a.oq[(size_t)h * HD + d] = (int8_t)q;
+        if (lane == 0) a.os[((size_t)h * HD + d) >> 6] = scale;
+    }
     if (a.of) a.of[(size_t)h * HD + d] = y;
+    MSTAMP(3);
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void k_attn_merge(Attn a_in) {
+    Attn a = a_in;
+    {
+        const int z = blockIdx.y;
+        a.ctl += z;
+        a.oq += (size_t)z * a.zs_oq;
+        a.os += (size_t)z * a.zs_os;
+        a.part += (size_t)z * a.zs_part;
+        if (a.of) a.of += (size_t)z * a.zs_of;
+    }
+    constexpr int GPH = HD / 64;                // quantisation groups per head
+    merge_group<HD, false>(a, blockIdx.x / GPH, blockIdx.x % GPH, threadIdx.x);
+}
+
+// ---- ATT_LONG: merge + Wo in ONE launch.  The K/V stream of the attention launch keeps HBM busy, so Wo cannot ride
+// along there; it rides with the merge instead: n_heads*HD/64 workgroups merge the chunk partials (one wave per 64
+// outputs, as k_attn_merge) while the other CUs pull their Wo rows into registers, then take the merged output as
+// tagged granules (wo_role) -- instead of a merge launch, a boundary and a Wo launch.
+template <int HD, int NJ, int RW>
+__global__ __launch_bounds__(256, 2) void k_merge_wo(Attn a, WoView w) {
+    __shared__ __attribute__((aligned(16))) int8_t lq[4096];
+    __shared__ __attribute__((aligned(16))) float ls[64];
+    __shared__ int flag;
+    constexpr int GPH = HD / 64;
+    const int nm = a.n_heads * GPH;                     // merge workgroups: ONE wave each (a wave pulls 16.6 KB of partials at
+    const int b = blockIdx.x;                           // 4096 positions; four of them behind one CU's queue took 2 us longer)
+    if (b < nm) {
+        if (threadIdx.x < 64) merge_group<HD, true>(a, b / GPH, b % GPH, threadIdx.x);
+        return;
+    }
+    wo_role<NJ, RW>(w, b - nm, lq, ls, &flag);
 }
 
 // ---- batched prompt ingestion: the k/v rows of a run of positions, ahead of a batched attn() ----
@@ -1047,6 +1098,7 @@ void kv_append(const Attn& a, int ntok, hipStream_t st) {
 // workgroups; fused, they split the d rows of Wo: rows per workgroup, wave-loads per row, rows per wave.
 // false = shape not covered (callers then launch attn() and the Wo GEMV separately).
 static int extra_workgroups(int n_att) { return n_att < 192 ? 256 - n_att : 64; }
+static int merge_workgroups(const Attn& a);
 static bool wo_geometry(const WoView& w, int n_att, int* rpw, int* nj, int* rw) {
     if (w.n % 64 || w.n > 4096 || w.d < 1) return false;
     const int nwo = extra_workgroups(n_att);
@@ -1063,10 +1115,40 @@ static int attn_slots(int chunk_slots, AttMode mode) {
 }
 bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode) {
     int rpw, nj, rw;
-    if (mode == ATT_LONG) return false;
     if (!(a.nz <= 1 && !a.of && !a.prepared && a.n_heads / a.n_kv <= Q3_MAXG && (a.hd == 128 || a.hd == 64))) return false;
     if (!w.W || !a.og || !a.epoch) return false;
-    return w.n == a.n_heads * a.hd && wo_geometry(w, a.n_kv * attn_slots(chunk_slots, mode), &rpw, &nj, &rw);
+    const int producers = mode == ATT_LONG ? merge_workgroups(a) : a.n_kv * attn_slots(chunk_slots, mode);
+    return w.n == a.n_heads * a.hd && w.n <= 4096 && wo_geometry(w, producers, &rpw, &nj, &rw);
+}
+
+// ATT_LONG: the merge + Wo launch behind the chunk launch
+static int merge_workgroups(const Attn& a) { return a.n_heads * (a.hd / 64); }
+template <int HD>
+static void launch_merge_wo(const Attn& a, WoView w, hipStream_t st) {
+    int rpw = 1, nj = 1, rw = 1;
+    const int nm = merge_workgroups(a), nwo = extra_workgroups(nm);
+    wo_geometry(w, nm, &rpw, &nj, &rw);
+    w.rpw = rpw;
+    const dim3 grid(nm + nwo), blk(256);
+#define Q3_MW(NJ, RW) hipLaunchKernelGGL((k_merge_wo<HD, NJ, RW>), grid, blk, 0, st, a, w)
+    switch (nj * 8 + rw) {
+        case 1 * 8 + 1: Q3_MW(1, 1); break;
+        case 1 * 8 + 2: Q3_MW(1, 2); break;
+        case 1 * 8 + 3: Q3_MW(1, 3); break;
+        case 1 * 8 + 4: Q3_MW(1, 4); break;
+        case 1 * 8 + 5: Q3_MW(1, 5); break;
+        case 2 * 8 + 1: Q3_MW(2, 1); break;
+        case 2 * 8 + 2: Q3_MW(2, 2); break;
+        case 2 * 8 + 3: Q3_MW(2, 3); break;
+        case 2 * 8 + 4: Q3_MW(2, 4); break;
+        case 2 * 8 + 5: Q3_MW(2, 5); break;
+        case 4 * 8 + 1: Q3_MW(4, 1); break;
+        case 4 * 8 + 2: Q3_MW(4, 2); break;
+        case 4 * 8 + 3: Q3_MW(4, 3); break;
+        case 4 * 8 + 4: Q3_MW(4, 4); break;
+        default: Q3_MW(4, 5); break;
+    }
+#undef Q3_MW
 }
 
 template <int HD, int HPW>
@@ -1110,11 +1192,11 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows
     const int nz = a.nz > 1 ? a.nz : 1;
     const bool two = a.n_heads / a.n_kv > 4;
     const int slots = attn_slots(chunk_slots, mode);
-    if (wo) {
-        if (!attn_wo_supported(a, *wo, chunk_slots, mode)) {
-            fprintf(stderr, "[q3hip] attention: fused Wo launch requested for a shape it does not cover\n");
-            exit(EXIT_FAILURE);
-        }
+    if (wo && !attn_wo_supported(a, *wo, chunk_slots, mode)) {
+        fprintf(stderr, "[q3hip] attention: fused Wo launch requested for a shape it does not cover\n");
+        exit(EXIT_FAILURE);
+    }
+    if (wo && mode != ATT_LONG) {
         if (a.hd == 128 && !two) launch_attn_wo<128, 1>(a, mode, rows_cap, slots, *wo, st);
         else if (a.hd == 128) launch_attn_wo<128, 2>(a, mode, rows_cap, slots, *wo, st);
         else if (!two) launch_attn_wo<64, 1>(a, mode, rows_cap, slots, *wo, st);
@@ -1146,7 +1228,10 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows
     else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
     else if (!two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
     else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
-    if (mode == ATT_LONG) {
+    if (mode == ATT_LONG && wo) {
+        if (a.hd == 128) launch_merge_wo<128>(a, *wo, st);
+        else launch_merge_wo<64>(a, *wo, st);
+    } else if (mode == ATT_LONG) {
         if (a.hd == 128) hipLaunchKernelGGL(k_attn_merge<128>, dim3(a.n_heads * 2, nz), dim3(64), 0, st, a);
         else hipLaunchKernelGGL(k_attn_merge<64>, dim3(a.n_heads, nz), dim3(64), 0, st, a);
     }

@@ -104,7 +104,8 @@ struct WoView {
 };
 // rows per consumer workgroup / whether the fused launch covers this shape (else: attn() then gemv())
 bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode);
-// `rows_cap`: see step_rows_cap (64 = whole tile).  `wo` non-null: the fused launch (ATT_SINGLE / ATT_MERGE only).
+// `rows_cap`: see step_rows_cap (64 = whole tile).  `wo` non-null: Wo rides along -- with the attention launch
+// (ATT_SINGLE / ATT_MERGE: k_attn_wo) or with the merge launch (ATT_LONG: k_merge_wo).
 void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows_cap = 64, const WoView* wo = nullptr);
 
 void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, hipStream_t st);

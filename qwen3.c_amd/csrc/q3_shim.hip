@@ -623,8 +623,9 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0, int rows_ca
     {   // head norms + RoPE + cache append + attention + quantise (forward.c:267-291)
         q3k::Attn a = attn_args(d, l, stream);
         bool fused = false;
-        if (d->fuse && mode != q3k::ATT_LONG) {
-            const q3k::WoView w = wo_view(d, l);
+        if (d->fuse) {
+            q3k::WoView w = wo_view(d, l);
+            if (mode == q3k::ATT_LONG) w.delay = 0;       // the merge is one round trip long: no reason to hold Wo back
             a.og = d->att_g; a.epoch = d->epoch; a.layer_tag = w.layer_tag;
             if (q3k::attn_wo_supported(a, w, d->chunk_slots, mode)) {
                 // attention AND Wo + residual in one launch (forward.c:267-298)
@@ -771,8 +772,15 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
     d->ctl_host->pos = pos;
     const bool pinned_ok = d->logits_pinned;
     if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
+        if (!d->gexec[q3k::step_shape(pos)]) {
+            // first step of this Model: capture EVERY launch shape its window can reach now, so that no later
+            // token pays for a graph instantiation when the position crosses into the next shape
+            static const int rep[Q3_STEP_SHAPES] = {0, 16, 32, 48, 64, Q3_ATT_LONG};
+            for (int k = 0; k < Q3_STEP_SHAPES; k++) {
+                if (!d->gexec[k] && (rep[k] < d->seq || k == q3k::step_shape(pos))) d->gexec[k] = build_graph(d, k == q3k::step_shape(pos) ? pos : rep[k], true);
+            }
+        }
         hipGraphExec_t& ex = d->gexec[q3k::step_shape(pos)];
-        if (!ex) ex = build_graph(d, pos, true);
         HIPCHK(hipGraphLaunch(ex, d->st));
         if (to_host) {
             wait_step(d);
@@ -1048,15 +1056,20 @@ __global__ void k_log_token(const int* tok, int* log_slot) { *log_slot = *tok; }
 void launch_stage(Dev* d, int pos, int stream) {
     const bool pinned_ok = true;
     if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
-        hipGraphExec_t& ex = d->pgexec[(size_t)stream * Q3_STEP_SHAPES + q3k::step_shape(pos)];
-        if (!ex) {
-            hipGraph_t graph = nullptr;
-            HIPCHK(hipStreamBeginCapture(d->st, hipStreamCaptureModeThreadLocal));
-            enqueue_step(d, pos, stream);
-            HIPCHK(hipStreamEndCapture(d->st, &graph));
-            HIPCHK(hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0));
-            HIPCHK(hipGraphDestroy(graph));
+        if (!d->pgexec[(size_t)stream * Q3_STEP_SHAPES + q3k::step_shape(pos)]) {
+            static const int rep[Q3_STEP_SHAPES] = {0, 16, 32, 48, 64, Q3_ATT_LONG};     // every shape at once: see run_step
+            for (int k = 0; k < Q3_STEP_SHAPES; k++) {
+                hipGraphExec_t& exk = d->pgexec[(size_t)stream * Q3_STEP_SHAPES + k];
+                if (exk || !(rep[k] < d->seq || k == q3k::step_shape(pos))) continue;
+                hipGraph_t graph = nullptr;
+                HIPCHK(hipStreamBeginCapture(d->st, hipStreamCaptureModeThreadLocal));
+                enqueue_step(d, k == q3k::step_shape(pos) ? pos : rep[k], stream);
+                HIPCHK(hipStreamEndCapture(d->st, &graph));
+                HIPCHK(hipGraphInstantiate(&exk, graph, nullptr, nullptr, 0));
+                HIPCHK(hipGraphDestroy(graph));
+            }
         }
+        hipGraphExec_t& ex = d->pgexec[(size_t)stream * Q3_STEP_SHAPES + q3k::step_shape(pos)];
         HIPCHK(hipGraphLaunch(ex, d->st));
     } else {
         enqueue_step(d, pos, stream);

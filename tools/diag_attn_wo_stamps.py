@@ -23,6 +23,18 @@ for pos in range(CTX, CTX + 40):
     if pos - CTX in (5, 20, 39):
         hip.q3_debug_stamps(m, buf, 8 * NWG)
         a = np.array(buf[:], dtype=np.int64).reshape(NWG, 8)
+        if pos >= 1024:      # k_merge_wo: 64 one-wave merge workgroups (marks 0 entry, 1 partials in, 2 sums done, 3 stored) + consumers
+            mg = np.array([w for w in range(64) if a[w, 3] >= a[w, 0] > 0])
+            con = np.array([w for w in range(64, 256) if a[w, 6] >= a[w, 0] > 0])
+            t0 = min(a[mg, 0].min(), a[con, 0].min())
+            print(f"pos {pos}: {len(mg)} merge + {len(con)} consumer workgroups (k_merge_wo); ns after the first entry")
+            rm = (a[mg, :4] - t0) * 10
+            for i in range(4):
+                print(f"  merge     mark {i}: min {rm[:, i].min():6d}  mean {rm[:, i].mean():8.0f}  max {rm[:, i].max():6d}")
+            rc = (a[con, :7] - t0) * 10
+            for i in range(7):
+                print(f"  consumer  mark {i}: min {rc[:, i].min():6d}  mean {rc[:, i].mean():8.0f}  max {rc[:, i].max():6d}")
+            continue
         nslots = 1 if pos < 64 else 16
         n_att = 8 * nslots
         att = np.array([w for w in range(n_att) if (w // 8) <= pos // 64 and a[w, 7] >= a[w, 0] > 0])
