@@ -159,6 +159,62 @@ __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks
     }
 }
 
+// ---- the K/V stream of the long-context launch is fetched by LOADER waves (waves 4-7 of a 512-thread workgroup).
+// A wave issues in order, so a compute wave that requests a 32-KB tile sits in the issue stage until the CU's
+// queue has taken it all in -- which is why k_attn holds the V requests back until the head norms are done, and the
+// V tile then lands behind the scores.  A loader wave has nothing else to do: it requests K AND V of its chunk back
+// to back (from the first instruction when the host vouches for the chunk: slot < sure_slots) as LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB = two cache rows per wave-instruction, straight into the tile, no registers), and
+// meets the compute waves at the barriers the one-role kernel has (K tile ready, V tile ready) once its share of
+// the tile has landed (counted vmcnt).  Row `pos` of the owning chunk is not in the cache yet: the DMA brings a stale
+// row, and the compute side overwrites it behind one extra barrier that only the owning workgroup takes.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <int HD>
+__device__ __forceinline__ void tile_dma(const float* src, float* tile, int uwave, int lane) {
+    constexpr int PIECES = Q3_ATT_CHUNK * HD * 4 / 1024;       // 1-KiB pieces of a tile: 32 at head_dim 128
+#pragma unroll
+    for (int j = 0; j < PIECES / 4; j++) {
+        const int p = uwave + 4 * j;                           // wave-uniform: the LDS address travels in M0
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 256 + lane * 4), (lptr_t)(tile + p * 256), 16, 0, 0);
+    }
+}
+template <int HD>
+__device__ __forceinline__ void tile_loader(const Attn& a, int g, int slot, int nslots, int sure_slots, float* Ks, float* Vs) {
+    constexpr int CH = Q3_ATT_CHUNK;
+    constexpr int PW = CH * HD * 4 / 1024 / 4;                 // pieces per loader wave and tile
+    static_assert(PW == 8 || PW == 4, "counted waits below assume 4 or 8 pieces per wave");
+    const int lane = threadIdx.x & 63;
+    const int uwave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 4;
+    const size_t cbase = (size_t)g * a.seq_len * HD;
+    const int pos = a.ctl->pos;
+    __builtin_amdgcn_s_barrier();             // E: the compute waves have their few requests in the queue
+    if (slot >= sure_slots && slot * CH > pos) return;
+    tile_dma<HD>(a.kc + cbase + (size_t)slot * CH * HD, Ks, uwave, lane);
+    tile_dma<HD>(a.vc + cbase + (size_t)slot * CH * HD, Vs, uwave, lane);
+    const int T = pos + 1;
+    const int nchunks = (T + CH - 1) / CH;
+    if (slot >= nchunks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in LDS after this workgroup is gone
+        return;
+    }
+    for (int c = slot; c < nchunks; c += nslots) {
+        const bool mine = pos >= c * CH && pos < (c + 1) * CH; // workgroup-uniform: this chunk holds the row of `pos`
+        if (c != slot) tile_dma<HD>(a.kc + cbase + (size_t)c * CH * HD, Ks, uwave, lane);    // every wave is past the scores of the previous chunk (barrier V)
+        if (c == slot) {
+            if (PW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // the K pieces are in; V still flies
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (mine) __builtin_amdgcn_s_barrier();                // the compute side now writes row `pos`
+        __builtin_amdgcn_s_barrier();                          // barrier K
+        if (c != slot) tile_dma<HD>(a.vc + cbase + (size_t)c * CH * HD, Vs, uwave, lane);    // the compute waves are past the PV of the previous chunk
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (mine) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                          // barrier V
+    }
+}
+
 // The attention stage as seen by ONE workgroup: kv head g, chunk slot `slot` of `nslots`.  Returns true
 // (workgroup-uniform) when THIS workgroup wrote the final outputs (codes + scales) of its kv head's query
 // heads: always in ATT_SINGLE, for the drawer of the last ticket in ATT_MERGE, never in ATT_LONG.
@@ -166,9 +222,15 @@ __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks
 // the host knows pos < rows_cap when it picks the launch, so the rows beyond are not even requested
 // (they used to be pulled, 64 KB per workgroup whatever pos was, through one CU that takes in ~24 KB/us).
 // HPW = query heads a wave may own (1 when the group has at most 4 query heads); PUB: see out_codes.
-template <int HD, int HPW, bool PUB>
+// LW = loader waves (0, or 4: the long-context launch, ATT_LONG only): the tiles are then fetched and parked by
+// tile_loader() on waves 4-7, and `rows_cap` carries sure_slots instead (chunk slots the host vouches for).
+template <int HD, int HPW, bool PUB, int LW = 0>
 __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int slot, int nslots, int rows_cap,
                                           float* Ks, float* Vs, int* last_flag_p) {
+    if (LW && threadIdx.x >= 256) {
+        tile_loader<HD>(a, g, slot, nslots, rows_cap, Ks, Vs);
+        return false;
+    }
     constexpr int L4 = HD / 4;               // lanes holding one head as float4
     constexpr int CH = Q3_ATT_CHUNK;
     constexpr int NLD = CH * L4 / 256;       // float4 loads per thread per tile
@@ -192,7 +254,7 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int s
     // Slot 0 always has work (chunk 0), so it requests its tile before `pos` has even arrived;
     // the other slots first learn whether their chunk exists -- a speculative 64 KB per idle
     // workgroup would cost tens of MB of useless HBM reads per layer at short contexts.
-    if (slot != 0 && slot * CH > pos) return false;
+    if (!LW && slot != 0 && slot * CH > pos) return false;
     const int tfirst = slot * CH;    // rows beyond pos are loaded but never used
     // At head_dim 128 a head is 32 lanes of float4, so ONE norm + rope pass serves two heads:
     // k of this step in the lower half of the wave, the wave's (first) query head in the upper
@@ -231,12 +293,18 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int s
     // Branch-free (a branch between loads makes the compiler lose count of vmcnt, and the head norms below would
     // wait for the whole tile): the tile is read through a buffer descriptor that ends after `rows_cap` rows, so
     // the requests for rows beyond it return zeros and move no bytes.
-    const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(a.kc + cbase + (size_t)tfirst * HD, 0, rows_cap * HD * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(a.vc + cbase + (size_t)tfirst * HD, 0, rows_cap * HD * 4, 0x00020000);
+    const int tile_rows = LW ? 0 : rows_cap;
+    const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(a.kc + cbase + (size_t)tfirst * HD, 0, tile_rows * HD * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(a.vc + cbase + (size_t)tfirst * HD, 0, tile_rows * HD * 4, 0x00020000);
+    if (LW) {
+        __builtin_amdgcn_s_barrier();         // E: these waves' requests are in the queue; the loader waves may flood it
+        if (slot >= rows_cap && slot * CH > pos) return false;
+    } else {
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-        const v4i r = __builtin_amdgcn_raw_buffer_load_b128(kres, (tid + k * 256) * 16, 0, 0);
-        kt[k] = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+        for (int k = 0; k < NLD; k++) {
+            const v4i r = __builtin_amdgcn_raw_buffer_load_b128(kres, (tid + k * 256) * 16, 0, 0);
+            kt[k] = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -292,10 +360,12 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int s
     // now the V tile: the K tile has landed (loads return in order), so these requests find
     // room in the CU's queue instead of parking the wave in the issue stage
     __builtin_amdgcn_sched_barrier(0);
+    if (!LW) {
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-        const v4i r = __builtin_amdgcn_raw_buffer_load_b128(vres, (tid + k * 256) * 16, 0, 0);
-        vt[k] = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+        for (int k = 0; k < NLD; k++) {
+            const v4i r = __builtin_amdgcn_raw_buffer_load_b128(vres, (tid + k * 256) * 16, 0, 0);
+            vt[k] = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     // wave 0 of the owning workgroup appends k and v of this step to the cache
@@ -315,7 +385,7 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int s
     for (int c = slot; c < nchunks; c += nslots) {
         const int t0 = c * CH;
         const int Tc = (T - t0 < CH) ? T - t0 : CH;      // valid positions in this chunk
-        if (!first) {      // contexts beyond nslots chunks only: the previous chunk's PV is over for this wave
+        if (!LW && !first) {      // contexts beyond nslots chunks only: the previous chunk's PV is over for this wave
             // (unconditional loads -- predicated accesses would push kt / vt out of registers -- with the
             // row clamped to the last valid one, so a short last chunk re-reads one row instead of
             // pulling 64 KB of unused cache)
@@ -340,17 +410,24 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int s
         // ---- K tile -> LDS (every wave is past the scores of the previous chunk: barrier V below).
         // The row of this very step comes from registers (select, no branch: the thread that
         // owns slice l4 of that row holds the same slice of kcur).
+        if (LW) {          // the loader waves' DMA fills the tile; row `pos` (not in the cache yet) comes from this wave's registers,
+            if (pos >= t0 && pos < t0 + CH) {      // once the DMA has landed (workgroup-uniform: the loaders take the same extra barrier)
+                __builtin_amdgcn_s_barrier();
+                if (wave == 0 && lane < L4) *reinterpret_cast<float4*>(Ks + (pos - t0) * HD + 4 * lane) = kcur_m;
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int idx = tid + k * 256;
-            const int t = idx / L4, l4 = idx - t * L4;
-            const bool cur = (t0 + t == pos);
-            float4 w = kt[k];
-            w.x = cur ? kcur_m.x : w.x;
-            w.y = cur ? kcur_m.y : w.y;
-            w.z = cur ? kcur_m.z : w.z;
-            w.w = cur ? kcur_m.w : w.w;
-            *reinterpret_cast<float4*>(Ks + t * HD + 4 * l4) = w;
+            for (int k = 0; k < NLD; k++) {
+                const int idx = tid + k * 256;
+                const int t = idx / L4, l4 = idx - t * L4;
+                const bool cur = (t0 + t == pos);
+                float4 w = kt[k];
+                w.x = cur ? kcur_m.x : w.x;
+                w.y = cur ? kcur_m.y : w.y;
+                w.z = cur ? kcur_m.z : w.z;
+                w.w = cur ? kcur_m.w : w.w;
+                *reinterpret_cast<float4*>(Ks + t * HD + 4 * l4) = w;
+            }
         }
         __syncthreads();                                  // barrier K
         STAMP(3);
@@ -398,17 +475,24 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int s
         STAMP(4);
         // ---- V tile -> LDS (it has been landing during the scores; every wave is past the
         //      PV of the previous chunk: barrier K above)
+        if (LW) {
+            if (pos >= t0 && pos < t0 + CH) {
+                __builtin_amdgcn_s_barrier();
+                if (wave == 0 && lane < L4) *reinterpret_cast<float4*>(Vs + (pos - t0) * HD + 4 * lane) = vraw_m;
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int idx = tid + k * 256;
-            const int t = idx / L4, l4 = idx - t * L4;
-            const bool cur = (t0 + t == pos);
-            float4 w = vt[k];
-            w.x = cur ? vraw_m.x : w.x;
-            w.y = cur ? vraw_m.y : w.y;
-            w.z = cur ? vraw_m.z : w.z;
-            w.w = cur ? vraw_m.w : w.w;
-            *reinterpret_cast<float4*>(Vs + t * HD + 4 * l4) = w;
+            for (int k = 0; k < NLD; k++) {
+                const int idx = tid + k * 256;
+                const int t = idx / L4, l4 = idx - t * L4;
+                const bool cur = (t0 + t == pos);
+                float4 w = vt[k];
+                w.x = cur ? vraw_m.x : w.x;
+                w.y = cur ? vraw_m.y : w.y;
+                w.z = cur ? vraw_m.z : w.z;
+                w.w = cur ? vraw_m.w : w.w;
+                *reinterpret_cast<float4*>(Vs + t * HD + 4 * l4) = w;
+            }
         }
         __syncthreads();                                  // barrier V
         STAMP(5);
@@ -506,6 +590,15 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int s
     }
     STAMP(7);
     return multi == ATT_SINGLE || (multi == ATT_MERGE && last_flag != 0);
+}
+
+// the long-context launch: four compute waves + four loader waves, two workgroups per CU
+template <int HD, int HPW>
+__global__ __launch_bounds__(512, 4) void k_attn_long(Attn a, int sure_slots) {
+    __shared__ __attribute__((aligned(16))) float Ks[Q3_ATT_CHUNK * HD];
+    __shared__ __attribute__((aligned(16))) float Vs[Q3_ATT_CHUNK * HD];
+    __shared__ int last_flag;
+    (void)attn_body<HD, HPW, false, 4>(a, (int)ATT_LONG, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, sure_slots, Ks, Vs, &last_flag);
 }
 
 template <int HD, int HPW>
@@ -1188,7 +1281,7 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows
         fprintf(stderr, "[q3hip] attention: head_dim %d not supported (64 or 128)\n", a.hd);
         exit(EXIT_FAILURE);
     }
-    if (rows_cap < 8 || rows_cap > Q3_ATT_CHUNK) rows_cap = Q3_ATT_CHUNK;
+    if (mode != ATT_LONG && (rows_cap < 8 || rows_cap > Q3_ATT_CHUNK)) rows_cap = Q3_ATT_CHUNK;
     const int nz = a.nz > 1 ? a.nz : 1;
     const bool two = a.n_heads / a.n_kv > 4;
     const int slots = attn_slots(chunk_slots, mode);
@@ -1224,10 +1317,22 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows
         return;
     }
     dim3 grid(a.n_kv, slots, nz);
-    if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn<128, 1>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
-    else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
-    else if (!two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
-    else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a, (int)mode, rows_cap);
+    static const bool long_loader = !(getenv("Q3_ATT_LOADER") && getenv("Q3_ATT_LOADER")[0] == '0');
+    if (mode == ATT_LONG && long_loader && a.hd == 128) {      // (head_dim 64: the one-role kernel; its general path does not fit 128 registers)
+        // chunk slots that hold cached positions for certain
+        // (16 per 1024 positions the shape has reached for certain: step_rows_cap; the op-level hook and every caller
+        // that does not say get 16 -- attn_mode() sent them here, so at least 1024 positions are cached)
+        int sure = rows_cap < Q3_ATT_LONG / Q3_ATT_CHUNK ? Q3_ATT_LONG / Q3_ATT_CHUNK : rows_cap;
+        if (sure > slots) sure = slots;
+        if (!two) hipLaunchKernelGGL((k_attn_long<128, 1>), grid, dim3(512), 0, st, a, sure);
+        else hipLaunchKernelGGL((k_attn_long<128, 2>), grid, dim3(512), 0, st, a, sure);
+    } else {
+        const int rc = mode == ATT_LONG ? Q3_ATT_CHUNK : rows_cap;       // the one-role kernel takes whole tiles in ATT_LONG
+        if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn<128, 1>), grid, dim3(256), 0, st, a, (int)mode, rc);
+        else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, (int)mode, rc);
+        else if (!two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, (int)mode, rc);
+        else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a, (int)mode, rc);
+    }
     if (mode == ATT_LONG && wo) {
         if (a.hd == 128) launch_merge_wo<128>(a, *wo, st);
         else launch_merge_wo<64>(a, *wo, st);

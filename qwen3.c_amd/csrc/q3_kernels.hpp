@@ -83,10 +83,15 @@ enum AttMode { ATT_SINGLE = 0, ATT_MERGE = 1, ATT_LONG = 2 };
 #define Q3_ATT_LONG 1024
 inline AttMode attn_mode(int pos) { return pos < 64 ? ATT_SINGLE : (pos < Q3_ATT_LONG ? ATT_MERGE : ATT_LONG); }
 // A step's launches are captured once per SHAPE: ATT_SINGLE comes in four, by the rows of the one K/V tile
-// that can hold cached positions (pos < 16, 32, 48, 64 -> rows_cap 16, 32, 48, 64: the rest is not requested).
-#define Q3_STEP_SHAPES 6
-inline int step_shape(int pos) { return pos < 64 ? pos / 16 : (pos < Q3_ATT_LONG ? 4 : 5); }
-inline int step_rows_cap(int pos) { return pos < 64 ? (pos / 16 + 1) * 16 : 64; }
+// that can hold cached positions (pos < 16, 32, 48, 64 -> rows_cap 16, 32, 48, 64: the rest is not requested);
+// ATT_LONG in one per 1024 positions, by the chunk slots that hold cached positions for certain (16 per 1024
+// positions reached: their workgroups request K/V without waiting for the position to arrive).
+inline int step_shape(int pos) { return pos < 64 ? pos / 16 : (pos < Q3_ATT_LONG ? 4 : 4 + pos / Q3_ATT_LONG); }
+inline int step_shapes(int seq_len) { return seq_len <= Q3_ATT_LONG ? 5 : 5 + (seq_len - 1) / Q3_ATT_LONG; }
+// what attn() gets as `rows_cap`: rows of the tile (one-chunk shapes), 64 (ATT_MERGE), sure chunk slots (ATT_LONG)
+inline int step_rows_cap(int pos) { return pos < 64 ? (pos / 16 + 1) * 16 : (pos < Q3_ATT_LONG ? 64 : (pos / Q3_ATT_LONG) * (Q3_ATT_LONG / 64)); }
+// a position of shape k (the first one)
+inline int step_shape_pos(int k) { return k < 4 ? 16 * k : (k == 4 ? 64 : (k - 4) * Q3_ATT_LONG); }
 
 // The Wo GEMV + residual add behind the attention, in the SAME launch (k_attn_wo in q3_attn.hip; reference
 // forward.c:291-298).
@@ -104,7 +109,7 @@ struct WoView {
 };
 // rows per consumer workgroup / whether the fused launch covers this shape (else: attn() then gemv())
 bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode);
-// `rows_cap`: see step_rows_cap (64 = whole tile).  `wo` non-null: Wo rides along -- with the attention launch
+// `rows_cap`: see step_rows_cap (one-chunk shapes: tile rows; ATT_LONG: chunk slots certain to exist, 16 when in doubt).  `wo` non-null: Wo rides along -- with the attention launch
 // (ATT_SINGLE / ATT_MERGE: k_attn_wo) or with the merge launch (ATT_LONG: k_merge_wo).
 void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows_cap = 64, const WoView* wo = nullptr);
 

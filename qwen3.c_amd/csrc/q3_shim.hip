@@ -135,11 +135,12 @@ struct Dev {
     int max_chunks = 1, chunk_slots = 1;
     bool logits_pinned = false;
     bool use_graph = true;
-    hipGraphExec_t gexec[Q3_STEP_SHAPES] = {};   // one per launch shape of a step (q3k::step_shape)
+    std::vector<hipGraphExec_t> gexec;    // one per launch shape of a step (q3k::step_shape)
+    int nshapes = 5;
     // pipeline / on-device loop: one KV cache per concurrent token stream
     int n_streams = 1;
     size_t cache_floats = 0;      // floats of one stream's K (or V) cache of one layer
-    std::vector<hipGraphExec_t> pgexec;   // [stream*Q3_STEP_SHAPES + shape], step without the ctl upload
+    std::vector<hipGraphExec_t> pgexec;   // [stream*nshapes + shape], step without the ctl upload
     int* ptokens = nullptr;       // last stage: [n_streams][cap] chosen tokens
     // fp16 contrast path (BASELINE config 5): weights dequantised to binary16 at attach, activations fp32
     bool fp16 = false;
@@ -417,7 +418,9 @@ Dev* attach(Model* m, const AttachOpts& opt = AttachOpts()) {
     if (d->loopback) {
         for (int i = 0; i < 2; i++) d->outbox[i] = dalloc<float>(d, d->dim + 1);
     }
-    d->pgexec.assign((size_t)d->n_streams * Q3_STEP_SHAPES, nullptr);
+    d->nshapes = q3k::step_shapes(d->seq);
+    d->gexec.assign((size_t)d->nshapes, nullptr);
+    d->pgexec.assign((size_t)d->n_streams * d->nshapes, nullptr);
     d->epoch = dalloc<unsigned>(d, 4);
     HIPCHK(hipMemsetAsync(d->epoch, 0, 4 * sizeof(unsigned), d->st));
     d->att_g = dalloc<unsigned long long>(d, (size_t)d->P / 4 + d->P / 64);
@@ -773,11 +776,13 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
     const bool pinned_ok = d->logits_pinned;
     if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
         if (!d->gexec[q3k::step_shape(pos)]) {
-            // first step of this Model: capture EVERY launch shape its window can reach now, so that no later
-            // token pays for a graph instantiation when the position crosses into the next shape
-            static const int rep[Q3_STEP_SHAPES] = {0, 16, 32, 48, 64, Q3_ATT_LONG};
-            for (int k = 0; k < Q3_STEP_SHAPES; k++) {
-                if (!d->gexec[k] && (rep[k] < d->seq || k == q3k::step_shape(pos))) d->gexec[k] = build_graph(d, k == q3k::step_shape(pos) ? pos : rep[k], true);
+            // first step of this Model: capture the launch shapes of the first Q3_ATT_LONG + 1024 positions now, so that
+            // no token pays for a graph instantiation when the position crosses into the next shape (beyond that: one
+            // instantiation per 1024 positions)
+            const int mine = q3k::step_shape(pos);
+            for (int k = 0; k < d->nshapes; k++) {
+                if (d->gexec[k] || !(k == mine || (k <= 5 && q3k::step_shape_pos(k) < d->seq))) continue;
+                d->gexec[k] = build_graph(d, k == mine ? pos : q3k::step_shape_pos(k), true);
             }
         }
         hipGraphExec_t& ex = d->gexec[q3k::step_shape(pos)];
@@ -1056,20 +1061,20 @@ __global__ void k_log_token(const int* tok, int* log_slot) { *log_slot = *tok; }
 void launch_stage(Dev* d, int pos, int stream) {
     const bool pinned_ok = true;
     if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
-        if (!d->pgexec[(size_t)stream * Q3_STEP_SHAPES + q3k::step_shape(pos)]) {
-            static const int rep[Q3_STEP_SHAPES] = {0, 16, 32, 48, 64, Q3_ATT_LONG};     // every shape at once: see run_step
-            for (int k = 0; k < Q3_STEP_SHAPES; k++) {
-                hipGraphExec_t& exk = d->pgexec[(size_t)stream * Q3_STEP_SHAPES + k];
-                if (exk || !(rep[k] < d->seq || k == q3k::step_shape(pos))) continue;
+        if (!d->pgexec[(size_t)stream * d->nshapes + q3k::step_shape(pos)]) {
+            const int mine = q3k::step_shape(pos);                    // the early shapes at once: see run_step
+            for (int k = 0; k < d->nshapes; k++) {
+                hipGraphExec_t& exk = d->pgexec[(size_t)stream * d->nshapes + k];
+                if (exk || !(k == mine || (k <= 5 && q3k::step_shape_pos(k) < d->seq))) continue;
                 hipGraph_t graph = nullptr;
                 HIPCHK(hipStreamBeginCapture(d->st, hipStreamCaptureModeThreadLocal));
-                enqueue_step(d, k == q3k::step_shape(pos) ? pos : rep[k], stream);
+                enqueue_step(d, k == mine ? pos : q3k::step_shape_pos(k), stream);
                 HIPCHK(hipStreamEndCapture(d->st, &graph));
                 HIPCHK(hipGraphInstantiate(&exk, graph, nullptr, nullptr, 0));
                 HIPCHK(hipGraphDestroy(graph));
             }
         }
-        hipGraphExec_t& ex = d->pgexec[(size_t)stream * Q3_STEP_SHAPES + q3k::step_shape(pos)];
+        hipGraphExec_t& ex = d->pgexec[(size_t)stream * d->nshapes + q3k::step_shape(pos)];
         HIPCHK(hipGraphLaunch(ex, d->st));
     } else {
         enqueue_step(d, pos, stream);
