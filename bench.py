@@ -399,7 +399,7 @@ def main():
                    "parallelism": "1 GPU" if ngpu == 1 else f"pp{ngpu}: layer pipeline, RCCL send/recv of the residual, "
                                                             f"{ngpu} concurrent streams"},
     }
-    out["config"]["launch"] = "hipGraph of per-stage kernels"
+    out["config"]["launch"] = "hipGraph of per-stage kernels: per layer qkv, attention+Wo (one launch), gate/up, down"
     out["rccl_comm_size"] = hip.q3_pipeline_size()
     bpt = hip.q3_bytes_per_token(C.byref(p), pos0 + W + K // 2)
     if args.dtype == "fp16":
@@ -468,7 +468,8 @@ def main():
                 t_tok = drop.sample(smp, drop.forward(md, t_tok, p_))
             out["dropin_loop_tokens_per_s"] = round(nd / (time.perf_counter() - t0), 2)
             out["dropin_loop"] = ("reference model_create + forward + host sample() (softmax export, qsort, xorshift) per token, "
-                                  "temperature 1e-6 / top-p 0.9, oracle/_ref/libqwen3_dropin.so")
+                                  "temperature 1e-6 / top-p 0.9, oracle/_ref/libqwen3_dropin.so; the reference's host qsort of "
+                                  f"{vocab} entries per token dominates this figure, not forward()")
             drop.sampler_free(smp)
             hip.q3_device_detach(md)
             drop.model_free(md)
@@ -494,7 +495,7 @@ def main():
         if args.model == "4B":
             # context for `value`: what the platform charges for this step's 182 dependent launches when every launch
             # only streams its stage's bytes (tools/micro/chain_floor.hip) -- a committed measurement, not re-run here
-            floor = chain_floor_from_log(os.path.join(ROOT, "profiles", "r02_chain_floor.log"))
+            floor = chain_floor_from_log(os.path.join(ROOT, "profiles", "r02_chain_floor.log"))      # (five launches per layer; the step now has four)
             if floor:
                 out["dependent_launch_floor"] = floor
         out["frac_of_measured_copy"] = round(per_gpu_rate * bpt / 1e9 / copy, 4)
@@ -526,18 +527,22 @@ def main():
             # bracket of the same launches is reported next to it
             us_best = dom.get("us_device_clock") or dom["us"]
             ach = round(dom_bytes / us_best / 1e3, 1)
-            traffic = None
+            traffic, traffic_check = None, None
             try:   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]["gateup"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]["gateup"]
                 if args.model == "4B":
                     traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
+                    # in-run check: the bytes this run prices the launch at against the committed counter figure
+                    ratio = traffic / float(dom_bytes)
+                    traffic_check = {"traffic_over_bytes_per_launch": round(ratio, 4), "within_3_percent": bool(abs(ratio - 1.0) <= 0.03)}
             except Exception:
                 pass
             out["roofline"] = {"bound": "hbm", "kernel": "k_gemv3<PRO_NORM,EPI_SWIGLU,3,8> (gate/up GEMV)",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "traffic_source": "profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+                               "traffic_source": "profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
                                                  "of this workload (FETCH_SIZE doubled per the gfx950 note), committed -- not re-measured by this run",
+                               "traffic_check": traffic_check,
                                "timing": "in-kernel device clock (s_memrealtime, first workgroup in .. last out) of the "
                                          "same launches that the HIP events bracket on the launch stream; "
                                          "us_per_launch_events includes the end-of-kernel release (~2 us)",

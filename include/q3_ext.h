@@ -231,6 +231,9 @@ int q3_debug_stamps(Model* m, unsigned long long* out, int n);
 /* Diagnostic: mean microseconds per launch of `iters` back-to-back launches of one GEMV class
  * ("qkv", "wo", "gateup", "down") cycling over layers [l_lo, l_hi). */
 double q3_debug_gemv_loop(Model* m, const char* which, int l_lo, int l_hi, int iters);
+/* Diagnostic: the same loop through the int8-MFMA GEMM of the prompt path on `ntok` (1..64) activation rows
+ * (ntok = 1: the decode GEMV's work on v_mfma_i32_16x16x64_i8, bit-identical results). */
+double q3_debug_gemm_loop(Model* m, const char* which, int ntok, int l_lo, int l_hi, int iters);
 
 const char* q3_version(void);
 

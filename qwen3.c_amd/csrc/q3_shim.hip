@@ -899,6 +899,11 @@ void rope_cs_host(int hd, int pos, std::vector<float>& cs) {
 
 }  // namespace
 
+namespace { void ensure_prefill(Dev* d); }
+#ifndef Q3_PF_CHUNK
+#define Q3_PF_CHUNK 64
+#endif
+
 // ============================================================ C ABI =========
 extern "C" {
 
@@ -945,6 +950,41 @@ double q3_debug_gemv_loop(Model* m, const char* which, int l_lo, int l_hi, int i
                 g.W = L.dn_q; g.S = L.dn_s; g.n = d->hid; g.d = d->dim;
                 g.xf = d->h; g.nw = nullptr; g.out = d->qkv;
                 q3k::gemv(g, q3k::PRO_F32, q3k::EPI_STORE, d->st);
+            }
+        }
+        HIPCHK(hipEventRecord(e1, d->st));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    HIPCHK(hipEventDestroy(e0));
+    HIPCHK(hipEventDestroy(e1));
+    return (double)ms * 1e3 / iters;
+}
+
+// diagnostic: the same back-to-back loop through the int8-MFMA GEMM of the prompt path (q3_prefill.hip) on `ntok`
+// quantised activation rows (1 = the decode GEMV's work on the matrix cores, bit-identical results): mean us per launch
+double q3_debug_gemm_loop(Model* m, const char* which, int ntok, int l_lo, int l_hi, int iters) {
+    Dev* d = lookup(m);
+    if (!d || d->fp16 || l_lo < d->l0 || l_hi > d->l1 || l_hi <= l_lo || iters <= 0 || ntok < 1 || ntok > Q3_PF_CHUNK) return -1.0;
+    HIPCHK(hipSetDevice(d->device));
+    ensure_prefill(d);
+    HIPCHK(hipMemsetAsync(d->pf_xq, 1, (size_t)Q3_PF_CHUNK * 64, d->st));       // any finite codes / scales will do for timing
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int pass = 0; pass < 2; pass++) {      // pass 0 warms up
+        HIPCHK(hipEventRecord(e0, d->st));
+        for (int i = 0; i < iters; i++) {
+            const LayerDev& L = d->layers[l_lo + i % (l_hi - l_lo)];
+            if (!strcmp(which, "qkv")) {
+                q3k::gemm_q8(L.qkv_q, L.qkv_s, d->dim, d->P + 2 * d->KVD, d->pf_xq, d->pf_xs, ntok, d->pf_qkv, d->P + 2 * d->KVD, q3k::EPI_STORE, d->st);
+            } else if (!strcmp(which, "wo")) {
+                q3k::gemm_q8(L.wo_q, L.wo_s, d->P, d->dim, d->pf_xq, d->pf_xs, ntok, d->pf_qkv, d->dim, q3k::EPI_STORE, d->st);
+            } else if (!strcmp(which, "gateup")) {
+                q3k::gemm_q8(L.gu_q, L.gu_s, d->dim, 2 * d->hid, d->pf_xq, d->pf_xs, ntok, d->pf_h, d->hid, q3k::EPI_SWIGLU, d->st);
+            } else {
+                q3k::gemm_q8(L.dn_q, L.dn_s, d->hid, d->dim, d->pf_xq, d->pf_xs, ntok, d->pf_qkv, d->dim, q3k::EPI_STORE, d->st);
             }
         }
         HIPCHK(hipEventRecord(e1, d->st));

@@ -240,6 +240,8 @@ def hip_lib():
         lib.q3_generate_sampled.argtypes = [ModelP, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         lib.q3_debug_gemv_loop.restype = C.c_double
         lib.q3_debug_gemv_loop.argtypes = [ModelP, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        lib.q3_debug_gemm_loop.restype = C.c_double
+        lib.q3_debug_gemm_loop.argtypes = [ModelP, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         lib.q3_debug_stamps.restype = C.c_int
         lib.q3_debug_stamps.argtypes = [ModelP, C.POINTER(C.c_uint64), C.c_int]
         lib.q3_pipeline_shutdown.restype = None

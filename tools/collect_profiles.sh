@@ -19,4 +19,6 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" -o w
 echo write done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats4096" -o k --output-format csv -- python3 "$REPO/bench.py" --context 4096 --steps 64 --warmup 8 $B > "$OUT/stats4096.log" 2>&1
 echo stats4096 done
-find "$OUT" -name "*.csv" | wc -l
+# keep what profiles/ needs (kernel statistics, counter rows); traces and databases stay on the box (gpurun merges <= 64 MiB)
+find "$OUT" -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.log" -delete
+du -sh "$OUT" | tail -1

@@ -5,7 +5,8 @@ import csv, glob, json, os, shutil, sys
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLASS = [("k_gemv3<1, 2,", "gateup"), ("k_gemv3<2, 1,", "down"), ("k_gemv3<1, 0,", "qkv"), ("k_gemv3<0, 1,", "wo"),
-         ("k_gemv2<", "cls"), ("k_attn<", "attn"), ("k_attn_merge", "attn_merge")]
+         ("k_gemv2<", "cls"), ("k_attn_wo<", "attn_wo"), ("k_merge_wo<", "merge_wo"), ("k_attn_long<", "attn_long"),
+         ("k_attn<", "attn"), ("k_attn_merge", "attn_merge")]
 ALG = {"gateup": 52920320, "down": 26460160, "qkv": 16711680, "wo": 11141120, "cls": 413265920}
 def per_kernel(pattern, counter):
     acc = {}
@@ -34,4 +35,6 @@ for name in fetch:
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+for f in glob.glob(os.path.join(src, "stats4096", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_ctx4096_kernel_stats.csv"))
 print(json.dumps(out["kernels"], indent=1))
