@@ -61,3 +61,48 @@ def test_decode_meets_the_oracle_past_1100_positions(hip, host, orc):
     Q.record_parity("4Bmini_decode_vs_tree_oracle_long", {"positions": n, "compared": compared, "bit_exact": True,
                                                           "attention_shapes": ["single", "merge", "long"]})
     hip.q3_model_close(mg); host.q3_model_close(mo)
+
+
+def test_in_launch_hand_off_under_foreign_load(hip):
+    """The attention -> Wo hand-off inside k_attn_wo / k_merge_wo (tagged granules, bounded polls) while ANOTHER
+    model's launches -- prompt passes on its own stream -- compete for the CUs and the memory system: the consumer
+    workgroups may start long before their attention workgroups get a CU, polls queue behind foreign traffic, the
+    chip is unevenly loaded.  Three hundred decode steps queued without a host sync in between (one-chunk shapes,
+    the in-launch merge and, with the window filled, the merge + Wo launch) must leave the logits of the same steps
+    run alone with separate attention and Wo launches (Q3_FUSE=0), bit for bit."""
+    import ctypes as C
+    import os
+    path = os.path.join(Q.tmp_dir(), "4Bmini_w2048.bin")
+    Q.synth("4Bmini", path, seq_len=2048)
+    rng = np.random.default_rng(41)
+    for T in (0, 1100):
+        feed = [int(t) for t in rng.integers(0, 8192, size=300)]
+        os.environ["Q3_FUSE"] = "0"
+        try:
+            mref = hip.q3_model_open(path.encode(), 1500, 0)
+            assert hip.q3_device_attach(mref) == 0
+        finally:
+            del os.environ["Q3_FUSE"]
+        if T:
+            hip.q3_kv_fill_random(mref, T, 3)
+        for k, tok in enumerate(feed):
+            hip.q3_forward_device(mref, tok, T + k)
+        hip.q3_logits_fetch(mref)
+        want = Q.logits_array(mref).copy()
+        hip.q3_model_close(mref)
+
+        ma = hip.q3_model_open(path.encode(), 1500, 0)      # fused launches (the default)
+        mb = hip.q3_model_open(path.encode(), 1500, 0)      # the foreign load
+        assert hip.q3_device_attach(ma) == 0 and hip.q3_device_attach(mb) == 0
+        if T:
+            hip.q3_kv_fill_random(ma, T, 3)
+        prompt = (C.c_int * 256)(*[int(t) for t in rng.integers(0, 8192, size=256)])
+        hip.q3_prefill(mb, prompt, 256, 0)                  # first use of its launch shapes, out of the way
+        for k, tok in enumerate(feed):
+            hip.q3_forward_device(ma, tok, T + k)           # queued on ma's stream, no sync
+            if k % 60 == 30:
+                hip.q3_prefill(mb, prompt, 256, 0)          # runs on mb's stream beside the queued steps; returns when done
+        hip.q3_logits_fetch(ma)
+        got = Q.logits_array(ma)
+        assert np.array_equal(got, want), f"context {T}"
+        hip.q3_model_close(ma); hip.q3_model_close(mb)
