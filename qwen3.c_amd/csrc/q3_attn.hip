@@ -224,9 +224,13 @@ __device__ __forceinline__ void tile_loader(const Attn& a, int g, int slot, int 
 // HPW = query heads a wave may own (1 when the group has at most 4 query heads); PUB: see out_codes.
 // LW = loader waves (0, or 4: the long-context launch, ATT_LONG only): the tiles are then fetched and parked by
 // tile_loader() on waves 4-7, and `rows_cap` carries sure_slots instead (chunk slots the host vouches for).
-template <int HD, int HPW, bool PUB, int LW = 0>
-__device__ __forceinline__ bool attn_body(const Attn& a, int multi, int g, int slot, int nslots, int rows_cap,
+// MODE >= 0: the launch shape (AttMode) at compile time -- the one-chunk kernel then carries neither the partials nor
+// the merge, and its registers and scalar spills are its own (the fused kernel slowed by 10 % in its one-chunk shape
+// when code was ADDED to its merge path: one kernel for all shapes pays every shape's register pressure); < 0: `multi`.
+template <int HD, int HPW, bool PUB, int LW = 0, int MODE = -1>
+__device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, int slot, int nslots, int rows_cap,
                                           float* Ks, float* Vs, int* last_flag_p) {
+    const int multi = MODE >= 0 ? MODE : multi_rt;
     if (LW && threadIdx.x >= 256) {
         tile_loader<HD>(a, g, slot, nslots, rows_cap, Ks, Vs);
         return false;
@@ -598,10 +602,10 @@ __global__ __launch_bounds__(512, 4) void k_attn_long(Attn a, int sure_slots) {
     __shared__ __attribute__((aligned(16))) float Ks[Q3_ATT_CHUNK * HD];
     __shared__ __attribute__((aligned(16))) float Vs[Q3_ATT_CHUNK * HD];
     __shared__ int last_flag;
-    (void)attn_body<HD, HPW, false, 4>(a, (int)ATT_LONG, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, sure_slots, Ks, Vs, &last_flag);
+    (void)attn_body<HD, HPW, false, 4, ATT_LONG>(a, (int)ATT_LONG, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, sure_slots, Ks, Vs, &last_flag);
 }
 
-template <int HD, int HPW>
+template <int HD, int HPW, int MODE>
 __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi, int rows_cap) {
     Attn a = a_in;
     {   // batched prompt ingestion: position blockIdx.z of the launch (all strides 0 for a decode step)
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi, int rows_
     __shared__ __attribute__((aligned(16))) float Ks[Q3_ATT_CHUNK * HD];
     __shared__ __attribute__((aligned(16))) float Vs[Q3_ATT_CHUNK * HD];
     __shared__ int last_flag;
-    (void)attn_body<HD, HPW, false>(a, multi, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, rows_cap, Ks, Vs, &last_flag);
+    (void)attn_body<HD, HPW, false, 0, MODE>(a, multi, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, rows_cap, Ks, Vs, &last_flag);
 }
 
 
@@ -759,7 +763,7 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
     WSTAMP(6);
 }
 
-template <int HD, int HPW, int NJ, int RW>
+template <int HD, int HPW, int NJ, int RW, int MODE>
 __global__ __launch_bounds__(256, 2) void k_attn_wo(Attn a, int multi, int rows_cap, int nslots, WoView w) {
     __shared__ __attribute__((aligned(16))) float Ks[Q3_ATT_CHUNK * HD];
     __shared__ __attribute__((aligned(16))) float Vs[Q3_ATT_CHUNK * HD];
@@ -767,7 +771,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_wo(Attn a, int multi, int rows_
     const int n_att = a.n_kv * nslots;
     const int b = blockIdx.x;
     if (b < n_att) {
-        const bool fin = attn_body<HD, HPW, true>(a, multi, b % a.n_kv, b / a.n_kv, nslots, rows_cap, Ks, Vs, &last_flag);
+        const bool fin = attn_body<HD, HPW, true, 0, MODE>(a, multi, b % a.n_kv, b / a.n_kv, nslots, rows_cap, Ks, Vs, &last_flag);
         (void)fin;      // its granules are the publication: nothing to drain, no flag to raise
         return;
     }
@@ -1251,7 +1255,8 @@ static void launch_attn_wo(const Attn& a, AttMode mode, int rows_cap, int slots,
     wo_geometry(w, n_att, &rpw, &nj, &rw);
     w.rpw = rpw;
     const dim3 grid(n_att + nwo), blk(256);
-#define Q3_AW(NJ, RW) hipLaunchKernelGGL((k_attn_wo<HD, HPW, NJ, RW>), grid, blk, 0, st, a, (int)mode, rows_cap, slots, w)
+#define Q3_AW(NJ, RW) do { if (mode == ATT_SINGLE) hipLaunchKernelGGL((k_attn_wo<HD, HPW, NJ, RW, ATT_SINGLE>), grid, blk, 0, st, a, (int)mode, rows_cap, slots, w); \
+                           else hipLaunchKernelGGL((k_attn_wo<HD, HPW, NJ, RW, ATT_MERGE>), grid, blk, 0, st, a, (int)mode, rows_cap, slots, w); } while (0)
     switch (nj * 8 + rw) {
         case 1 * 8 + 1: Q3_AW(1, 1); break;
         case 1 * 8 + 2: Q3_AW(1, 2); break;
@@ -1328,10 +1333,14 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows
         else hipLaunchKernelGGL((k_attn_long<128, 2>), grid, dim3(512), 0, st, a, sure);
     } else {
         const int rc = mode == ATT_LONG ? Q3_ATT_CHUNK : rows_cap;       // the one-role kernel takes whole tiles in ATT_LONG
-        if (a.hd == 128 && !two) hipLaunchKernelGGL((k_attn<128, 1>), grid, dim3(256), 0, st, a, (int)mode, rc);
-        else if (a.hd == 128) hipLaunchKernelGGL((k_attn<128, 2>), grid, dim3(256), 0, st, a, (int)mode, rc);
-        else if (!two) hipLaunchKernelGGL((k_attn<64, 1>), grid, dim3(256), 0, st, a, (int)mode, rc);
-        else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a, (int)mode, rc);
+#define Q3_KA(HD_, HPW_) do { if (mode == ATT_SINGLE) hipLaunchKernelGGL((k_attn<HD_, HPW_, ATT_SINGLE>), grid, dim3(256), 0, st, a, (int)mode, rc); \
+                              else if (mode == ATT_MERGE) hipLaunchKernelGGL((k_attn<HD_, HPW_, ATT_MERGE>), grid, dim3(256), 0, st, a, (int)mode, rc); \
+                              else hipLaunchKernelGGL((k_attn<HD_, HPW_, ATT_LONG>), grid, dim3(256), 0, st, a, (int)mode, rc); } while (0)
+        if (a.hd == 128 && !two) Q3_KA(128, 1);
+        else if (a.hd == 128) Q3_KA(128, 2);
+        else if (!two) Q3_KA(64, 1);
+        else Q3_KA(64, 2);
+#undef Q3_KA
     }
     if (mode == ATT_LONG && wo) {
         if (a.hd == 128) launch_merge_wo<128>(a, *wo, st);
