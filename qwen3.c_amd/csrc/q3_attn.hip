@@ -231,6 +231,8 @@ template <int HD, int HPW, bool PUB, int LW = 0, int MODE = -1>
 __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, int slot, int nslots, int rows_cap,
                                           float* Ks, float* Vs, int* last_flag_p) {
     const int multi = MODE >= 0 ? MODE : multi_rt;
+    // (the op-level hook's `prepared` inputs never reach the fused kernel: attn_wo_supported)
+    const bool prepared = PUB ? false : a.prepared != 0;
     if (LW && threadIdx.x >= 256) {
         tile_loader<HD>(a, g, slot, nslots, rows_cap, Ks, Vs);
         return false;
@@ -275,7 +277,7 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
         vraw = *reinterpret_cast<const float4*>(a.qkv + P + KVD + (size_t)g * HD + 4 * l);     // slice l in both halves
         if (HPW > 1 && lane < L4 && wave + 4 < kv_mul)
             qraw[HPW - 1] = *reinterpret_cast<const float4*>(a.qkv + (size_t)(g * kv_mul + wave + 4) * HD + 4 * lane);
-        if (!a.prepared) {
+        if (!prepared) {
             kg = *reinterpret_cast<const float4*>((half ? a.qnw : a.knw) + 4 * l);
             if (HPW > 1 && lane < L4) qg = *reinterpret_cast<const float4*>(a.qnw + 4 * lane);
         }
@@ -287,12 +289,12 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
             const int i = wave + 4 * hi;
             if (i < kv_mul) qraw[hi] = *reinterpret_cast<const float4*>(a.qkv + (size_t)(g * kv_mul + i) * HD + 4 * lane);
         }
-        if (!a.prepared) {
+        if (!prepared) {
             qg = *reinterpret_cast<const float4*>(a.qnw + 4 * lane);
             kg = *reinterpret_cast<const float4*>(a.knw + 4 * lane);
         }
     }
-    if (!a.prepared) rope_slices<HD>(a.cs, FUSE ? l : lane, ca, cb);
+    if (!prepared) rope_slices<HD>(a.cs, FUSE ? l : lane, ca, cb);
     __builtin_amdgcn_sched_barrier(0);
     // Branch-free (a branch between loads makes the compiler lose count of vmcnt, and the head norms below would
     // wait for the whole tile): the tile is read through a buffer descriptor that ends after `rows_cap` rows, so
@@ -323,7 +325,7 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
     float4 kcur_m, vraw_m = vraw, q4[HPW];
     if constexpr (FUSE) {
         float4 r = kraw;
-        if (!a.prepared) r = headnorm_rope_halves<HD>(kraw, kg, ca, cb, l);
+        if (!prepared) r = headnorm_rope_halves<HD>(kraw, kg, ca, cb, l);
         const float ox = lane_xor_f<32>(r.x), oy = lane_xor_f<32>(r.y), oz = lane_xor_f<32>(r.z), ow = lane_xor_f<32>(r.w);
         const float4 other = make_float4(ox, oy, oz, ow);
         kcur_m = half ? other : r;
@@ -331,7 +333,7 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
         if (HPW > 1) {
             q4[HPW - 1] = qraw[HPW - 1];
             if (wave + 4 < kv_mul) {
-                if (!a.prepared) q4[HPW - 1] = headnorm_rope_vals<HD>(q4[HPW - 1], qg, ca, cb, lane);
+                if (!prepared) q4[HPW - 1] = headnorm_rope_vals<HD>(q4[HPW - 1], qg, ca, cb, lane);
                 const float ax = lane_xor_f<32>(q4[HPW - 1].x), ay = lane_xor_f<32>(q4[HPW - 1].y);
                 const float az = lane_xor_f<32>(q4[HPW - 1].z), aw = lane_xor_f<32>(q4[HPW - 1].w);
                 if (half) q4[HPW - 1] = make_float4(ax, ay, az, aw);
@@ -339,7 +341,7 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
         }
     } else {
         float4 kcur = kraw;
-        if (!a.prepared) kcur = headnorm_rope_vals<HD>(kraw, kg, ca, cb, lane);
+        if (!prepared) kcur = headnorm_rope_vals<HD>(kraw, kg, ca, cb, lane);
         // L4 == 16: lane's slice is lane % 16; lanes 16..63 fetch it from lane % 16
         const int src = (lane & (L4 - 1)) << 2;
         kcur_m.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(kcur.x)));
@@ -354,7 +356,7 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
         for (int hi = 0; hi < HPW; hi++) {
             q4[hi] = qraw[hi];
             if (wave + 4 * hi < kv_mul) {
-                if (!a.prepared) q4[hi] = headnorm_rope_vals<HD>(q4[hi], qg, ca, cb, lane);
+                if (!prepared) q4[hi] = headnorm_rope_vals<HD>(q4[hi], qg, ca, cb, lane);
                 const float ox = lane_xor_f<32>(q4[hi].x), oy = lane_xor_f<32>(q4[hi].y);
                 const float oz = lane_xor_f<32>(q4[hi].z), ow = lane_xor_f<32>(q4[hi].w);
                 if (half) q4[hi] = make_float4(ox, oy, oz, ow);
