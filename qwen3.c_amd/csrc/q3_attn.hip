@@ -1204,7 +1204,8 @@ static bool wo_geometry(const WoView& w, int n_att, int* rpw, int* nj, int* rw) 
     *rpw = (w.d + nwo - 1) / nwo;
     *nj = (w.n + 1023) / 1024;
     *rw = (*rpw + 3) / 4;
-    return (*nj == 1 || *nj == 2 || *nj == 4) && *rw <= 5 && *rw * *nj <= 20;
+    // (up to 8 rows of 4 KiB per wave = 160 registers of tile: the 8B shapes' in-launch-merge launch, 32 rows per consumer)
+    return (*nj == 1 || *nj == 2 || *nj == 4) && (*rw <= 5 || (*nj == 4 && *rw <= 8));
 }
 static int attn_slots(int chunk_slots, AttMode mode) {
     // ATT_MERGE serves positions below Q3_ATT_LONG only: never more than Q3_ATT_LONG / 64 chunks, so the
@@ -1214,7 +1215,8 @@ static int attn_slots(int chunk_slots, AttMode mode) {
 }
 bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode) {
     int rpw, nj, rw;
-    if (!(a.nz <= 1 && !a.of && !a.prepared && a.n_heads / a.n_kv <= Q3_MAXG && (a.hd == 128 || a.hd == 64))) return false;
+    // (head_dim 128 only -- every Qwen3 size; the head_dim-64 test shapes take the separate launches)
+    if (!(a.nz <= 1 && !a.of && !a.prepared && a.n_heads / a.n_kv <= Q3_MAXG && a.hd == 128)) return false;
     if (!w.W || !a.og || !a.epoch) return false;
     const int producers = mode == ATT_LONG ? merge_workgroups(a) : a.n_kv * attn_slots(chunk_slots, mode);
     return w.n == a.n_heads * a.hd && w.n <= 4096 && wo_geometry(w, producers, &rpw, &nj, &rw);
@@ -1245,7 +1247,10 @@ static void launch_merge_wo(const Attn& a, WoView w, hipStream_t st) {
         case 4 * 8 + 2: Q3_MW(4, 2); break;
         case 4 * 8 + 3: Q3_MW(4, 3); break;
         case 4 * 8 + 4: Q3_MW(4, 4); break;
-        default: Q3_MW(4, 5); break;
+        case 4 * 8 + 5: Q3_MW(4, 5); break;
+        case 4 * 8 + 6: Q3_MW(4, 6); break;
+        case 4 * 8 + 7: Q3_MW(4, 7); break;
+        default: Q3_MW(4, 8); break;
     }
 #undef Q3_MW
 }
@@ -1274,7 +1279,10 @@ static void launch_attn_wo(const Attn& a, AttMode mode, int rows_cap, int slots,
         case 4 * 8 + 4: Q3_AW(4, 4); break;
         case 1 * 8 + 5: Q3_AW(1, 5); break;
         case 2 * 8 + 5: Q3_AW(2, 5); break;
-        default: Q3_AW(4, 5); break;
+        case 4 * 8 + 5: Q3_AW(4, 5); break;
+        case 4 * 8 + 6: Q3_AW(4, 6); break;
+        case 4 * 8 + 7: Q3_AW(4, 7); break;
+        default: Q3_AW(4, 8); break;
     }
 #undef Q3_AW
 }
@@ -1297,10 +1305,8 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows
         exit(EXIT_FAILURE);
     }
     if (wo && mode != ATT_LONG) {
-        if (a.hd == 128 && !two) launch_attn_wo<128, 1>(a, mode, rows_cap, slots, *wo, st);
-        else if (a.hd == 128) launch_attn_wo<128, 2>(a, mode, rows_cap, slots, *wo, st);
-        else if (!two) launch_attn_wo<64, 1>(a, mode, rows_cap, slots, *wo, st);
-        else launch_attn_wo<64, 2>(a, mode, rows_cap, slots, *wo, st);
+        if (!two) launch_attn_wo<128, 1>(a, mode, rows_cap, slots, *wo, st);
+        else launch_attn_wo<128, 2>(a, mode, rows_cap, slots, *wo, st);
         return;
     }
     if (nz > 1) {
@@ -1345,8 +1351,7 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows
 #undef Q3_KA
     }
     if (mode == ATT_LONG && wo) {
-        if (a.hd == 128) launch_merge_wo<128>(a, *wo, st);
-        else launch_merge_wo<64>(a, *wo, st);
+        launch_merge_wo<128>(a, *wo, st);
     } else if (mode == ATT_LONG) {
         if (a.hd == 128) hipLaunchKernelGGL(k_attn_merge<128>, dim3(a.n_heads * 2, nz), dim3(64), 0, st, a);
         else hipLaunchKernelGGL(k_attn_merge<64>, dim3(a.n_heads, nz), dim3(64), 0, st, a);
