@@ -18,6 +18,16 @@
 // When pos >= 64 every workgroup publishes its chunk partials (m_c, l_c, O_c) and the one that
 // draws the last ticket of its kv head merges them inside the same launch; below
 // that the kernel normalises and quantises directly.
+//
+// Kernels of a decode step (one per launch shape, q3_kernels.hpp step_shape):
+//   k_attn_wo     < 1024 cached positions: the attention workgroups above AND, on the CUs they leave idle, the Wo
+//                 GEMV + residual (forward.c:292-298) -- its rows wait in registers and take the attention output
+//                 as tagged 8-byte granules inside the launch
+//   k_attn_long   >= 1024: the same attention arithmetic with the K/V tiles fetched by four loader waves per
+//                 workgroup as LDS-DMA; partials to HBM
+//   k_merge_wo    >= 1024: merge of the chunk partials (one wave per 64 outputs) + the Wo consumers in one launch
+//   k_attn, k_attn_merge   the separate forms (Q3_FUSE=0, head_dim 64, op-level hooks, the fp16 path)
+//   k_attn_block, k_kv_append   the batched prompt pass (q3_prefill)
 #include <cstdio>
 #include <cstdlib>
 
