@@ -245,13 +245,16 @@ __global__ __launch_bounds__(256) void k_argmax_part(const float* __restrict__ l
         pi[blockIdx.x] = idx;
     }
 }
-__global__ __launch_bounds__(64) void k_argmax_final(const float* pv, const int* pi, int* out, int* out2) {
+__global__ __launch_bounds__(64) void k_argmax_final(const float* pv, const int* pi, int n, int* out, int* out2) {
     const int lane = threadIdx.x;
     float v = pv[lane];
     int idx = pi[lane];
     argmax_merge(v, idx, pv[lane + 64], pi[lane + 64]);
     for (int m = 32; m >= 1; m >>= 1) argmax_merge(v, idx, __shfl_xor(v, m, 64), __shfl_xor(idx, m, 64));
     if (lane == 0) {
+        // no logit compared greater than anything (all NaN: a broken checkpoint): the pick feeds the next step's embedding
+        // fetch on the device, so it must stay a valid token id
+        if ((unsigned)idx >= (unsigned)n) idx = 0;
         *out = idx;
         if (out2) *out2 = idx;
     }
@@ -260,7 +263,7 @@ void argmax(const float* logits, int n, float* scratch /* 2*128 words */, int* o
     float* pv = scratch;
     int* pi = reinterpret_cast<int*>(scratch + Q3_ARGMAX_WGS);
     hipLaunchKernelGGL(k_argmax_part, dim3(Q3_ARGMAX_WGS), dim3(256), 0, st, logits, n, pv, pi);
-    hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(64), 0, st, pv, pi, out, out2);
+    hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(64), 0, st, pv, pi, n, out, out2);
 }
 
 __global__ __launch_bounds__(64) void k_rmsnorm(float* out, const float* x, const float* w, int n) {
