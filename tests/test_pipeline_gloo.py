@@ -77,12 +77,15 @@ def _stage_worker(rank, world, path, nsteps, port, q):
     dist.destroy_process_group()
 
 
-def test_two_stage_pipeline_over_gloo_matches_single_process():
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipeline_over_gloo_matches_single_process(world):
+    """world = 2: the two-stage case; world = 3: one layer per stage on the 3-layer model, the token returning from
+    rank 2 to rank 0 across two idle hops of the ring"""
     import torch.multiprocessing as mp
     host, orc = Q.host_lib(), Q.oracle_lib()
     path = os.path.join(Q.tmp_dir(), "small.bin")
     Q.synth("small", path)
-    nsteps, world = 6, 2
+    nsteps = 6
     m = host.q3_model_open(path.encode(), 0, 1)
     orc.orc_set_mode(Q.ORC_TREE); orc.orc_set_threads(1)
     want, tok = [], 7
@@ -92,7 +95,7 @@ def test_two_stage_pipeline_over_gloo_matches_single_process():
     host.q3_model_close(m)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 300
+    port = 29600 + (os.getpid() * 7 + world) % 300
     procs = [ctx.Process(target=_stage_worker, args=(r, world, path, nsteps, port, q)) for r in range(world)]
     for p in procs:
         p.start()
