@@ -111,3 +111,22 @@ def test_loader_rejects_bad_files(host):
 def test_argmax_is_first_maximum(host):
     a = np.array([1, 5, 5, 2], np.float32)
     assert host.q3_argmax(Q.fptr(a), 4) == 1
+
+
+def test_host_argmax_first_maximum_with_ties_and_nans():
+    """q3_argmax (SSE2 / AVX2 picked at run time) == the scalar walk `if (x[i] > best)` from the left: first of
+    equal maxima, NaNs never win, lengths around the vector widths and the full vocabulary."""
+    host = Q.host_lib()
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 31, 32, 33, 63, 64, 65, 127, 1000, 151936):
+        for trial in range(12):
+            y = rng.standard_normal(n).astype(np.float32)
+            if trial % 3 == 0 and n > 3:
+                y[rng.integers(0, n, 3)] = y.max()
+            if trial % 4 == 1 and n > 5:
+                y[rng.integers(1, n)] = np.nan
+            want, best = 0, y[0]
+            for i in range(1, n):
+                if y[i] > best:
+                    best, want = y[i], i
+            assert host.q3_argmax(Q.fptr(y), n) == want, (n, trial)
