@@ -653,8 +653,11 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi, int rows_
 // every one resident, attention first in dispatch order, and every wait is bounded: a consumer
 // that gives up raises *err (host-visible) and the host stops with a message.
 
-#ifndef Q3_SPIN_LIMIT
-#define Q3_SPIN_LIMIT (1u << 21)     // polls of >= 0.3 us each: a second or more before giving up
+// A wait inside a launch gives up after this much DEVICE time (s_memrealtime, 100 MHz): far beyond anything a
+// healthy launch takes -- also when another process's kernels hold the attention workgroups' CUs for a while -- and
+// short of what a watchdog would call a hung GPU.  (A count of polls would expire sooner the faster the polls return.)
+#ifndef Q3_WAIT_TICKS
+#define Q3_WAIT_TICKS 500000000ull   // 5 s
 #endif
 
 // The attention chain does all its memory round trips in its first ~3.5 us (position, q/k/v, K tile, V tile); weight
@@ -717,7 +720,7 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
     unsigned sval = 0;
     int ok = 1;
     {
-        unsigned spins = 0;
+        const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
         for (;;) {
             bool hit = true;
             if (tid < ncode) {
@@ -727,7 +730,7 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
             }
             if (__all(hit)) break;
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > Q3_SPIN_LIMIT) { ok = 0; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t_wait > Q3_WAIT_TICKS) { ok = 0; break; }
         }
         WSTAMP(3);
         while (ok) {
@@ -747,7 +750,7 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
                 hit = hit && (unsigned)(x >> 32) == tag;
             }
             if (__all(hit)) break;
-            if (++spins > Q3_SPIN_LIMIT) { ok = 0; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t_wait > Q3_WAIT_TICKS) { ok = 0; break; }
         }
     }
 #pragma unroll
