@@ -48,6 +48,12 @@ namespace q3k {
 
 typedef __attribute__((address_space(1))) unsigned g_u32;
 
+// a word that an EARLIER launch wrote (position, step counter), fetched by s_load through the scalar cache
+// (volatile: the request stays where it is written, ahead of the vector loads; only the wait moves to the use)
+__device__ __forceinline__ int ld_scalar(const int* p) {
+    return *(const volatile __attribute__((address_space(4))) int*)(p);
+}
+
 
 // write-through 8-byte store / cache-bypassing loads for data handed to another workgroup
 // inside the launch
@@ -197,7 +203,7 @@ __device__ __forceinline__ void tile_loader(const Attn& a, int g, int slot, int 
     const int lane = threadIdx.x & 63;
     const int uwave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 4;
     const size_t cbase = (size_t)g * a.seq_len * HD;
-    const int pos = a.ctl->pos;
+    const int pos = ld_scalar(&a.ctl->pos);
     __builtin_amdgcn_s_barrier();             // E: the compute waves have their few requests in the queue
     if (slot >= sure_slots && slot * CH > pos) return;
     tile_dma<HD>(a.kc + cbase + (size_t)slot * CH * HD, Ks, uwave, lane);
@@ -264,13 +270,12 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
     // in only ~40 KB of requests at once): the step's raw q/k/v + norm weights + (cos,sin) row,
     // the K tile (32 KB at head_dim 128), which lands while the head norms run, and after the
     // norms the V tile, which streams in while the scores and the softmax are being computed.
-    const int pos = a.ctl->pos;
-    const unsigned tag = PUB ? ((*a.epoch << 8) | a.layer_tag) : 0u;
+    // The position and the step counter travel on the SCALAR path (s_load: its own counter, its own
+    // cache), so waiting for them never waits for a vector load -- as a vector load in front of the
+    // early exit below, `pos` cost a whole memory round trip before anything else was even requested.
+    const int pos = ld_scalar(&a.ctl->pos);
+    const unsigned tag = PUB ? (((unsigned)ld_scalar(reinterpret_cast<const int*>(a.epoch)) << 8) | a.layer_tag) : 0u;
     float4 kt[NLD], vt[NLD];
-    // Slot 0 always has work (chunk 0), so it requests its tile before `pos` has even arrived;
-    // the other slots first learn whether their chunk exists -- a speculative 64 KB per idle
-    // workgroup would cost tens of MB of useless HBM reads per layer at short contexts.
-    if (!LW && slot != 0 && slot * CH > pos) return false;
     const int tfirst = slot * CH;    // rows beyond pos are loaded but never used
     // At head_dim 128 a head is 32 lanes of float4, so ONE norm + rope pass serves two heads:
     // k of this step in the lower half of the wave, the wave's (first) query head in the upper
@@ -310,6 +315,11 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
     // wait for the whole tile): the tile is read through a buffer descriptor that ends after `rows_cap` rows, so
     // the requests for rows beyond it return zeros and move no bytes.
     const int tile_rows = LW ? 0 : rows_cap;
+    // Slot 0 always has work (chunk 0), so it requests its tile before `pos` has even arrived;
+    // the other slots first learn whether their chunk exists -- a speculative 64 KB per idle
+    // workgroup would cost tens of MB of useless HBM reads per layer at short contexts.  (Their few
+    // small requests above are already out; the one-chunk shape has no other slot.)
+    if (MODE != ATT_SINGLE && !LW && slot != 0 && slot * CH > pos) return false;
     const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(a.kc + cbase + (size_t)tfirst * HD, 0, tile_rows * HD * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(a.vc + cbase + (size_t)tfirst * HD, 0, tile_rows * HD * 4, 0x00020000);
     if (LW) {
@@ -323,9 +333,13 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    // The head norms below start HERE, behind the tile requests: the instruction selector orders pure arithmetic
+    // freely inside a basic block (sched_barrier binds only the machine scheduler), and with no branch in between
+    // it had put the wait for k/q and the whole norm chain in front of the K-tile requests.
+    asm volatile("" : "+v"(kraw.x), "+v"(kraw.y), "+v"(kraw.z), "+v"(kraw.w) :: "memory");
 
     const int T = pos + 1;
-    const int nchunks = (T + CH - 1) / CH;
+    const int nchunks = MODE == ATT_SINGLE ? 1 : (T + CH - 1) / CH;     // (the one-chunk shape: pos < 64, slot 0)
     if (slot >= nchunks) return false;
     STAMP(1);
     const bool owner = ((nchunks - 1) % nslots) == slot;
@@ -682,6 +696,9 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
     WSTAMP(0);
     const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = w.n;
+    // the step counter is read FIRST: loads return in issue order, so a load of it placed behind the weight requests
+    // (where the tag is needed) made the first poll wait for every Wo row of the wave
+    const unsigned tag = ((unsigned)__builtin_amdgcn_readfirstlane((int)*w.epoch) << 8) | w.layer_tag;
     // rows of this wave: wb*rpw + uwave*RW + r while uwave*RW + r < rpw; the others are aimed past the matrix
     // (rows >= d read as zero through the descriptor and move no bytes)
     int rows[RW];
@@ -712,7 +729,6 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
     // only its lanes' FIRST granule (a few lines per poll, so that 256 waiting workgroups do not load the fabric the
     // attention chain's own round trips go through), then sweeps the rest until every tag matches.  Bounded.
     constexpr int NG = NJ;                       // code granules per thread: (n/4) / 256 <= NJ
-    const unsigned tag = (*w.epoch << 8) | w.layer_tag;
     const int ncode = n >> 2, nscale = n >> 6;
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     const g_u64* gr = (const g_u64*)w.gran;
@@ -721,33 +737,34 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
     int ok = 1;
     {
         const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+        // Every load below is unconditional (indices clamped to a granule of the same kind; the compare is masked
+        // instead): behind `if (i < ncode)` each load became an exec-masked block ending in s_waitcnt vmcnt(0), and
+        // a sweep cost one memory round trip PER GRANULE of a thread instead of one in all.
+        const int i0 = tid < ncode ? tid : ncode - 1;
         for (;;) {
-            bool hit = true;
-            if (tid < ncode) {
-                const unsigned long long x = __hip_atomic_load(gr + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                val[0] = (unsigned)x;
-                hit = (unsigned)(x >> 32) == tag;
-            }
+            const unsigned long long x = __hip_atomic_load(gr + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            val[0] = (unsigned)x;
+            const bool hit = (unsigned)(x >> 32) == tag;
             if (__all(hit)) break;
             __builtin_amdgcn_s_sleep(4);
             if (__builtin_amdgcn_s_memrealtime() - t_wait > Q3_WAIT_TICKS) { ok = 0; break; }
         }
         WSTAMP(3);
+        const int is = ncode + (tid < nscale ? tid : nscale - 1);
         while (ok) {
-            bool hit = true;
+            unsigned long long x[NG];
 #pragma unroll
             for (int k = 1; k < NG; k++) {
                 const int i = tid + 256 * k;
-                if (i < ncode) {
-                    const unsigned long long x = __hip_atomic_load(gr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    val[k] = (unsigned)x;
-                    hit = hit && (unsigned)(x >> 32) == tag;
-                }
+                x[k] = __hip_atomic_load(gr + (i < ncode ? i : ncode - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (tid < nscale) {
-                const unsigned long long x = __hip_atomic_load(gr + ncode + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sval = (unsigned)x;
-                hit = hit && (unsigned)(x >> 32) == tag;
+            const unsigned long long xs = __hip_atomic_load(gr + is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool hit = (unsigned)(xs >> 32) == tag;
+            sval = (unsigned)xs;
+#pragma unroll
+            for (int k = 1; k < NG; k++) {
+                val[k] = (unsigned)x[k];
+                hit = hit && (unsigned)(x[k] >> 32) == tag;
             }
             if (__all(hit)) break;
             if (__builtin_amdgcn_s_memrealtime() - t_wait > Q3_WAIT_TICKS) { ok = 0; break; }
@@ -786,7 +803,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_wo(Attn a, int multi, int rows_
     const int n_att = a.n_kv * nslots;
     const int b = blockIdx.x;
     if (b < n_att) {
-        const bool fin = attn_body<HD, HPW, true, 0, MODE>(a, multi, b % a.n_kv, b / a.n_kv, nslots, rows_cap, Ks, Vs, &last_flag);
+        const bool fin = attn_body<HD, HPW, true, 0, MODE>(a, multi, MODE == ATT_SINGLE ? b : b % a.n_kv, MODE == ATT_SINGLE ? 0 : b / a.n_kv,
+                                                           MODE == ATT_SINGLE ? 1 : nslots, rows_cap, Ks, Vs, &last_flag);
         (void)fin;      // its granules are the publication: nothing to drain, no flag to raise
         return;
     }
@@ -1062,9 +1080,9 @@ __device__ __forceinline__ void merge_group(const Attn& a, int h, int grp, int l
     float o0[64];
 #pragma unroll
     for (int k = 0; k < 64; k++) o0[k] = base[(size_t)(k < rmax ? k : rmax) * ST + d];
-    const int nchunks = a.ctl->pos / Q3_ATT_CHUNK + 1;
+    const int nchunks = ld_scalar(&a.ctl->pos) / Q3_ATT_CHUNK + 1;
     unsigned tag = 0;
-    if (PUB) tag = (*a.epoch << 8) | a.layer_tag;
+    if (PUB) tag = ((unsigned)ld_scalar(reinterpret_cast<const int*>(a.epoch)) << 8) | a.layer_tag;
     if (lane >= nchunks) ml0 = make_float2(-3.0e38f, 0.0f);
     float M = wave_max(ml0.x);
     MSTAMP(1);

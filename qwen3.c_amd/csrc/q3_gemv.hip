@@ -250,39 +250,40 @@ __device__ __forceinline__ void release_stream_waves() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// 16 bytes at byte offset `off` of a buffer; past the end of the descriptor: zeros, no memory traffic
+__device__ __forceinline__ float4 ld_f4(__amdgpu_buffer_rsrc_t r, int off) {
+    const v4i t = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__int_as_float(t.x), __int_as_float(t.y), __int_as_float(t.z), __int_as_float(t.w));
+}
+
 template <int PRO>
 __device__ __forceinline__ void prepare_activation(const Gemv& a, int nid, int NN, int lane, int8_t* lq, float* ls) {
     const int n = a.n;
     if (PRO == PRO_NORM) {
+        // Branch-free loads through buffer descriptors that end at n floats: a lane past the end reads zeros and
+        // moves no bytes.  (Written as `if (i < n) v = load`, every load became its own exec-masked block that
+        // ENDS WITH s_waitcnt vmcnt(0): twelve dependent memory round trips in front of the barrier.)
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xf), 0, n * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.nw), 0, n * 4, 0x00020000);
         float4 own[QN], gw[QN];
 #pragma unroll
         for (int k = 0; k < QN; k++) {                    // the blocks this wave quantises, and their norm weights
             const int i = (nid + k * NN) * 256 + 4 * lane;
-            own[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            gw[k] = own[k];
-            if (i < n) {
-                own[k] = *reinterpret_cast<const float4*>(a.xf + i);
-                gw[k] = *reinterpret_cast<const float4*>(a.nw + i);
-            }
+            own[k] = ld_f4(xr, i * 4);
+            gw[k] = ld_f4(gr, i * 4);
         }
         float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;     // SUM256 over all of x, every preparing wave redundantly
         for (int b0 = 0; b0 * 256 < n; b0 += XR) {
             float4 v[XR];
 #pragma unroll
-            for (int u = 0; u < XR; u++) {
-                const int i = (b0 + u) * 256 + 4 * lane;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < n) v[u] = *reinterpret_cast<const float4*>(a.xf + i);
-            }
+            for (int u = 0; u < XR; u++) v[u] = ld_f4(xr, ((b0 + u) * 256 + 4 * lane) * 4);
             if (b0 == 0) release_stream_waves();
 #pragma unroll
-            for (int u = 0; u < XR; u++) {
-                if ((b0 + u) * 256 + 4 * lane < n) {
-                    c0 = c0 + v[u].x * v[u].x;
-                    c1 = c1 + v[u].y * v[u].y;
-                    c2 = c2 + v[u].z * v[u].z;
-                    c3 = c3 + v[u].w * v[u].w;
-                }
+            for (int u = 0; u < XR; u++) {                // c + 0*0 == c exactly: slots past n change nothing
+                c0 = c0 + v[u].x * v[u].x;
+                c1 = c1 + v[u].y * v[u].y;
+                c2 = c2 + v[u].z * v[u].z;
+                c3 = c3 + v[u].w * v[u].w;
             }
         }
         const float ss = bfly64((c0 + c1) + (c2 + c3));
@@ -306,13 +307,10 @@ __device__ __forceinline__ void prepare_activation(const Gemv& a, int nid, int N
             }
         }
     } else if (PRO == PRO_F32) {
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.xf), 0, n * 4, 0x00020000);
         float4 xo[QF];
 #pragma unroll
-        for (int k = 0; k < QF; k++) {
-            const int i = (nid + k * NN) * 256 + 4 * lane;
-            xo[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < n) xo[k] = *reinterpret_cast<const float4*>(a.xf + i);
-        }
+        for (int k = 0; k < QF; k++) xo[k] = ld_f4(xr, ((nid + k * NN) * 256 + 4 * lane) * 4);
         release_stream_waves();
 #pragma unroll
         for (int k = 0; k < QF; k++) {
