@@ -740,29 +740,35 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
         // Every load below is unconditional (indices clamped to a granule of the same kind; the compare is masked
         // instead): behind `if (i < ncode)` each load became an exec-masked block ending in s_waitcnt vmcnt(0), and
         // a sweep cost one memory round trip PER GRANULE of a thread instead of one in all.
-        const int i0 = tid < ncode ? tid : ncode - 1;
-        for (;;) {
-            const unsigned long long x = __hip_atomic_load(gr + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val[0] = (unsigned)x;
-            const bool hit = (unsigned)(x >> 32) == tag;
-            if (__all(hit)) break;
-            __builtin_amdgcn_s_sleep(4);
-            if (__builtin_amdgcn_s_memrealtime() - t_wait > Q3_WAIT_TICKS) { ok = 0; break; }
+        // Poll (w.poll, experiments): 0 = every wave re-reads its lanes' first code granules (granules 0..255: two kv
+        // heads' worth); 1 = every wave the scale granules; 2 = ONE wave per workgroup polls a 64-granule block picked
+        // by the workgroup index (the others park at the barrier): 1/4 of the requests, spread over all lines.
+        const int pm = w.poll & 3;
+        int is = pm == 1 ? ncode + tid % nscale : (pm == 2 ? ((wb * 64) % (ncode + nscale - 63)) + lane : (tid < ncode ? tid : ncode - 1));
+        const int nap = w.poll >> 2;
+        if (pm != 2 || uwave == 0) {
+            for (;;) {
+                const unsigned long long x = __hip_atomic_load(gr + is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool hit = (unsigned)(x >> 32) == tag;
+                if (__all(hit)) break;
+                if (nap == 0) __builtin_amdgcn_s_sleep(2); else if (nap == 1) __builtin_amdgcn_s_sleep(8); else if (nap == 2) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(100);
+                if (__builtin_amdgcn_s_memrealtime() - t_wait > Q3_WAIT_TICKS) { ok = 0; break; }
+            }
         }
+        if (pm == 2) __builtin_amdgcn_s_barrier();
         WSTAMP(3);
-        const int is = ncode + (tid < nscale ? tid : nscale - 1);
         while (ok) {
             unsigned long long x[NG];
 #pragma unroll
-            for (int k = 1; k < NG; k++) {
+            for (int k = 0; k < NG; k++) {
                 const int i = tid + 256 * k;
                 x[k] = __hip_atomic_load(gr + (i < ncode ? i : ncode - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            const unsigned long long xs = __hip_atomic_load(gr + is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long xs = __hip_atomic_load(gr + ncode + (tid < nscale ? tid : nscale - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool hit = (unsigned)(xs >> 32) == tag;
             sval = (unsigned)xs;
 #pragma unroll
-            for (int k = 1; k < NG; k++) {
+            for (int k = 0; k < NG; k++) {
                 val[k] = (unsigned)x[k];
                 hit = hit && (unsigned)(x[k] >> 32) == tag;
             }

@@ -277,7 +277,7 @@ __device__ __forceinline__ void prepare_activation(const Gemv& a, int nid, int N
             float4 v[XR];
 #pragma unroll
             for (int u = 0; u < XR; u++) v[u] = ld_f4(xr, ((b0 + u) * 256 + 4 * lane) * 4);
-            if (b0 == 0) release_stream_waves();
+            if (b0 == 0) { GSTAMP(1); release_stream_waves(); GSTAMP(4); }
 #pragma unroll
             for (int u = 0; u < XR; u++) {                // c + 0*0 == c exactly: slots past n change nothing
                 c0 = c0 + v[u].x * v[u].x;
@@ -286,8 +286,16 @@ __device__ __forceinline__ void prepare_activation(const Gemv& a, int nid, int N
                 c3 = c3 + v[u].w * v[u].w;
             }
         }
+#ifdef Q3_GEMV_STAMPS
+        asm volatile("" : "+v"(c0));
+        GSTAMP(2);
+#endif
         const float ss = bfly64((c0 + c1) + (c2 + c3));
         const float sc = 1.0f / sqrtf(ss / (float)n + 1e-6f);
+#ifdef Q3_GEMV_STAMPS
+        { float t_ = sc; asm volatile("" : "+v"(t_)); }
+        GSTAMP(5);
+#endif
 #pragma unroll
         for (int k = 0; k < QN; k++) {
             const int blk = nid + k * NN;                  // wave-uniform
@@ -367,7 +375,7 @@ static void prep_waves(Pro pro, int n, int& lo, int& hi) {
 }
 
 template <int PRO, int EPI, int NJ, int R>
-__global__ __launch_bounds__(1024) void k_gemv3(Gemv a, int ntasks, int tw, int early8) {
+__global__ __launch_bounds__(1024) void k_gemv3(Gemv a, int ntasks, int tw, int early8, int tq, int tr, int nn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NL = R * NJ;
     // look-ahead of the streaming loop: the whole tile when it is small (the launch is then bound by
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(1024) void k_gemv3(Gemv a, int ntasks, int tw, int 
     // the preparing waves are the FIRST waves of the workgroup: they start first, and their few
     // loads enter the CU's memory pipeline ahead of the weight requests (a load issued behind
     // the weight burst waits ~2.5 us in that queue)
-    const int nn = (int)(blockDim.x >> 6) - tw;
+    // nn = preparing waves = waves of the workgroup - tw (from the host: blockDim is one more scalar load away)
     if (uwave < nn) {
         prepare_activation<PRO>(a, uwave, nn, lane, lq, ls);
         GSTAMP(3);
@@ -394,9 +402,12 @@ __global__ __launch_bounds__(1024) void k_gemv3(Gemv a, int ntasks, int tw, int 
         return;
     }
 
-    // tasks are dealt evenly: workgroup i owns [i*ntasks/G, (i+1)*ntasks/G), at most tw of them
-    const int tfirst = (int)(((long long)blockIdx.x * ntasks) / gridDim.x);
-    const int tcount = (int)(((long long)(blockIdx.x + 1) * ntasks) / gridDim.x) - tfirst;
+    // tasks are dealt evenly: with tq = ntasks / G and tr = ntasks % G (from the host: two 64-bit divisions here were
+    // ~260 instructions on every streaming wave's way to its first request), the first tr workgroups own tq + 1
+    // consecutive tasks, the others tq -- at most tw of them either way
+    const int bx = (int)blockIdx.x;
+    const int tfirst = bx * tq + (bx < tr ? bx : tr);
+    const int tcount = tq + (bx < tr ? 1 : 0);
     int task = (uwave - nn < tcount) ? tfirst + (uwave - nn) : ntasks;   // rows >= d read as zero through the descriptor
     const int row0 = task * R;
     float res[R];
@@ -407,7 +418,9 @@ __global__ __launch_bounds__(1024) void k_gemv3(Gemv a, int ntasks, int tw, int 
     const WView wd = make_wview(a);
     Tile<R, NJ> T;
     const TileLane tl = tile_lane<NJ>(wd, lane);
+    GSTAMP(2);
     release_stream_waves();
+    GSTAMP(3);
     // A CU takes in ~40 KB of requests at once and ~27 KB/us after the first bytes are back
     // (~2 us); a wave that tries to request more just sits in the issue stage, and the barrier
     // below would wait for it.  So only as much as the CU accepts by the time the activation is
@@ -593,7 +606,7 @@ static void launch_one(const Gemv& g, const Plan& p, hipStream_t st) {
     } else {
         const size_t lds = (size_t)g.n + (size_t)(g.n / 64) * 4;
         hipLaunchKernelGGL((k_gemv3<PRO, EPI, NJ, R>), dim3(p.grid), dim3(p.NW * 64), lds, st, g, ntasks, p.TW,
-                           early8_for(p.TW));
+                           early8_for(p.TW), ntasks / p.grid, ntasks % p.grid, p.NW - p.TW);
     }
 }
 

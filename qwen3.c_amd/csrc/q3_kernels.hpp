@@ -106,6 +106,7 @@ struct WoView {
     unsigned* err;        // host-mapped word, set to 1 when a bounded wait gives up
     unsigned long long* stamps;   // diagnostic builds only (-DQ3_ATTN_STAMPS): eight device-clock marks per consumer workgroup
     int delay;            // device-clock ticks (10 ns) the extra workgroups hold their weight requests back after entry
+    int poll;             // experiments (Q3_WO_POLL): how the consumers wait, see wo_role
 };
 // rows per consumer workgroup / whether the fused launch covers this shape (else: attn() then gemv())
 bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode);

@@ -129,7 +129,7 @@ struct Dev {
     unsigned long long* att_g = nullptr;   // attention output as {tag, value} granules [P/4 + P/64] (fused launch)
     unsigned* err_host = nullptr; // host-mapped: [0] set by a consumer whose bounded wait gave up
     bool fuse = true;             // attention + Wo in one launch below Q3_ATT_LONG cached positions (Q3_FUSE=0: separate launches)
-    int pf_delay = 250;           // x 10 ns: how long the consumer workgroups of k_attn_wo hold their Wo requests back (Q3_WO_DELAY)
+    int pf_delay = 150;           // x 10 ns: how long the consumer workgroups of k_attn_wo hold their Wo requests back (Q3_WO_DELAY)
     unsigned long long* stamps = nullptr;
     int* amax_host = nullptr;
     int max_chunks = 1, chunk_slots = 1;
@@ -600,6 +600,7 @@ q3k::WoView wo_view(Dev* d, int l) {
     w.x = d->x;
     w.gran = d->att_g; w.epoch = d->epoch; w.layer_tag = (unsigned)(l & 255) + 1u;
     w.delay = d->pf_delay;
+    { static const int pm = getenv("Q3_WO_POLL") ? atoi(getenv("Q3_WO_POLL")) : 2; w.poll = pm; }
     w.stamps = d->stamps;
     HIPCHK(hipHostGetDevicePointer((void**)&w.err, d->err_host, 0));
     return w;

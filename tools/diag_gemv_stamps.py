@@ -19,7 +19,7 @@ if not os.path.exists(path): Q.synth(mdl, path)
 m = hip.q3_model_open(path.encode(), 1024, 0)
 hip.q3_debug_stamps.argtypes = [Q.ModelP, C.POINTER(C.c_uint64), C.c_int]
 tok = 9707
-names = ["entry", "issued", "x->lds", "prologue", "barrier", "bar1", "dotted", "end"]
+names = ["entry", "issued", "x-in|atbar", "prologue|released", "barrier", "scale", "dotted", "end"]
 for pos in range(40):
     lg = hip.forward(m, tok, pos); tok = hip.q3_argmax(lg, 151936)
     if pos in (5, 20, 39):
