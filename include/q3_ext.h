@@ -89,6 +89,10 @@ int q3_device_attach(Model* m);
 int q3_device_attach_fp16(Model* m);
 void q3_device_detach(Model* m);
 void q3_device_sync(Model* m);
+/* Below 1024 cached positions attention and the Wo GEMV share one launch whose Wo workgroups wait, bounded, for the
+ * attention output inside the launch.  Should such a wait ever give up (5 s of device time), the Model switches to
+ * separate launches, redoes whatever was queued since its last synchronisation, and goes on; this counts how often. */
+int q3_handoff_fallbacks(Model* m);
 /* One decode step without the logits copy: logits stay on the device.
  * Pair with q3_logits_fetch() or q3_device_argmax(). */
 void q3_forward_device(Model* m, int token, int pos);

@@ -30,6 +30,7 @@
 //   k_attn_block, k_kv_append   the batched prompt pass (q3_prefill)
 #include <cstdio>
 #include <cstdlib>
+#include <unordered_map>
 
 #include "q3_device.hpp"
 #include "q3_kernels.hpp"
@@ -752,7 +753,7 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
                 const bool hit = (unsigned)(x >> 32) == tag;
                 if (__all(hit)) break;
                 if (nap == 0) __builtin_amdgcn_s_sleep(2); else if (nap == 1) __builtin_amdgcn_s_sleep(8); else if (nap == 2) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(100);
-                if (__builtin_amdgcn_s_memrealtime() - t_wait > Q3_WAIT_TICKS) { ok = 0; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t_wait > w.wait_ticks) { ok = 0; break; }
             }
         }
         if (pm == 2) __builtin_amdgcn_s_barrier();
@@ -773,7 +774,7 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
                 hit = hit && (unsigned)(x[k] >> 32) == tag;
             }
             if (__all(hit)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t_wait > Q3_WAIT_TICKS) { ok = 0; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t_wait > w.wait_ticks) { ok = 0; break; }
         }
     }
 #pragma unroll
@@ -1233,7 +1234,9 @@ void kv_append(const Attn& a, int ntok, hipStream_t st) {
 // queue the attention chain's dependent loads wait in (measured: +1.7 us on the stage).  So nwo = 256 - n_att extra
 // workgroups; fused, they split the d rows of Wo: rows per workgroup, wave-loads per row, rows per wave.
 // false = shape not covered (callers then launch attn() and the Wo GEMV separately).
-static int extra_workgroups(int n_att) { return n_att < 192 ? 256 - n_att : 64; }
+// (cu_count(): the device's compute units, q3_kernels.hpp -- never a literal: the waits inside the launch rely on every
+// workgroup of the grid being resident at once)
+static int extra_workgroups(int n_att) { const int ncu = cu_count(); return n_att < ncu * 3 / 4 ? ncu - n_att : ncu / 4; }
 static int merge_workgroups(const Attn& a);
 static bool wo_geometry(const WoView& w, int n_att, int* rpw, int* nj, int* rw) {
     if (w.n % 64 || w.n > 4096 || w.d < 1) return false;
@@ -1250,15 +1253,96 @@ static int attn_slots(int chunk_slots, AttMode mode) {
     const int merge_slots = chunk_slots < Q3_ATT_LONG / Q3_ATT_CHUNK ? chunk_slots : Q3_ATT_LONG / Q3_ATT_CHUNK;
     return mode == ATT_SINGLE ? 1 : (mode == ATT_MERGE ? merge_slots : chunk_slots);
 }
+static const void* fused_kernel(const Attn& a, const WoView& w, int chunk_slots, AttMode mode, int* grid, int* rpw_out);
+static bool grid_resident(const void* kernel, int grid);
 bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode) {
     int rpw, nj, rw;
     // (head_dim 128 only -- every Qwen3 size; the head_dim-64 test shapes take the separate launches)
     if (!(a.nz <= 1 && !a.of && !a.prepared && a.n_heads / a.n_kv <= Q3_MAXG && a.hd == 128)) return false;
     if (!w.W || !a.og || !a.epoch) return false;
     const int producers = mode == ATT_LONG ? merge_workgroups(a) : a.n_kv * attn_slots(chunk_slots, mode);
-    return w.n == a.n_heads * a.hd && w.n <= 4096 && wo_geometry(w, producers, &rpw, &nj, &rw);
+    if (!(w.n == a.n_heads * a.hd && w.n <= 4096 && producers < cu_count() && wo_geometry(w, producers, &rpw, &nj, &rw))) return false;
+    int grid = 0;
+    const void* kern = fused_kernel(a, w, chunk_slots, mode, &grid, nullptr);
+    if (!grid_resident(kern, grid)) {
+        static bool told = false;
+        if (!told) fprintf(stderr, "[q3hip] the fused attention + Wo launch (%d workgroups) would not be resident at once on this device: separate launches\n", grid);
+        told = true;
+        return false;
+    }
+    return true;
 }
 
+// ---- the fused launches by function pointer: the same pointer serves the residency check and the launch ----
+typedef void (*MergeWoFn)(Attn, WoView);
+typedef void (*AttnWoFn)(Attn, int, int, int, WoView);
+template <int HD>
+static MergeWoFn pick_merge_wo(int nj, int rw) {
+#define Q3_MW(NJ, RW) return k_merge_wo<HD, NJ, RW>
+    switch (nj * 8 + rw) {
+        case 1 * 8 + 1: Q3_MW(1, 1);
+        case 1 * 8 + 2: Q3_MW(1, 2);
+        case 1 * 8 + 3: Q3_MW(1, 3);
+        case 1 * 8 + 4: Q3_MW(1, 4);
+        case 1 * 8 + 5: Q3_MW(1, 5);
+        case 2 * 8 + 1: Q3_MW(2, 1);
+        case 2 * 8 + 2: Q3_MW(2, 2);
+        case 2 * 8 + 3: Q3_MW(2, 3);
+        case 2 * 8 + 4: Q3_MW(2, 4);
+        case 2 * 8 + 5: Q3_MW(2, 5);
+        case 4 * 8 + 1: Q3_MW(4, 1);
+        case 4 * 8 + 2: Q3_MW(4, 2);
+        case 4 * 8 + 3: Q3_MW(4, 3);
+        case 4 * 8 + 4: Q3_MW(4, 4);
+        case 4 * 8 + 5: Q3_MW(4, 5);
+        case 4 * 8 + 6: Q3_MW(4, 6);
+        case 4 * 8 + 7: Q3_MW(4, 7);
+        default: Q3_MW(4, 8);
+    }
+#undef Q3_MW
+}
+template <int HD, int HPW>
+static AttnWoFn pick_attn_wo(int nj, int rw, AttMode mode) {
+#define Q3_AW(NJ, RW) return mode == ATT_SINGLE ? (AttnWoFn)k_attn_wo<HD, HPW, NJ, RW, ATT_SINGLE> : (AttnWoFn)k_attn_wo<HD, HPW, NJ, RW, ATT_MERGE>
+    switch (nj * 8 + rw) {
+        case 1 * 8 + 1: Q3_AW(1, 1);
+        case 1 * 8 + 2: Q3_AW(1, 2);
+        case 1 * 8 + 3: Q3_AW(1, 3);
+        case 1 * 8 + 4: Q3_AW(1, 4);
+        case 1 * 8 + 5: Q3_AW(1, 5);
+        case 2 * 8 + 1: Q3_AW(2, 1);
+        case 2 * 8 + 2: Q3_AW(2, 2);
+        case 2 * 8 + 3: Q3_AW(2, 3);
+        case 2 * 8 + 4: Q3_AW(2, 4);
+        case 2 * 8 + 5: Q3_AW(2, 5);
+        case 4 * 8 + 1: Q3_AW(4, 1);
+        case 4 * 8 + 2: Q3_AW(4, 2);
+        case 4 * 8 + 3: Q3_AW(4, 3);
+        case 4 * 8 + 4: Q3_AW(4, 4);
+        case 4 * 8 + 5: Q3_AW(4, 5);
+        case 4 * 8 + 6: Q3_AW(4, 6);
+        case 4 * 8 + 7: Q3_AW(4, 7);
+        default: Q3_AW(4, 8);
+    }
+#undef Q3_AW
+}
+// The consumers of a fused launch spin on granules that other workgroups of the SAME launch write: that only ends if
+// every workgroup of the grid holds a CU at once.  Checked per kernel against the runtime's occupancy answer (cached);
+// one workgroup per CU is all these grids ask for, so a grid of at most cu_count() workgroups is resident when the
+// answer is at least 1.  The bounded waits and the host's fallback (q3_shim.hip: sync_checked) stay as the backstop.
+static bool grid_resident(const void* kernel, int grid) {
+    static std::unordered_map<const void*, int> cache;
+    auto it = cache.find(kernel);
+    int per_cu;
+    if (it != cache.end()) {
+        per_cu = it->second;
+    } else {
+        per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess) per_cu = 0;
+        cache[kernel] = per_cu;
+    }
+    return per_cu >= 1 && grid <= per_cu * cu_count();
+}
 // ATT_LONG: the merge + Wo launch behind the chunk launch
 static int merge_workgroups(const Attn& a) { return a.n_heads * (a.hd / 64); }
 template <int HD>
@@ -1268,28 +1352,8 @@ static void launch_merge_wo(const Attn& a, WoView w, hipStream_t st) {
     wo_geometry(w, nm, &rpw, &nj, &rw);
     w.rpw = rpw;
     const dim3 grid(nm + nwo), blk(256);
-#define Q3_MW(NJ, RW) hipLaunchKernelGGL((k_merge_wo<HD, NJ, RW>), grid, blk, 0, st, a, w)
-    switch (nj * 8 + rw) {
-        case 1 * 8 + 1: Q3_MW(1, 1); break;
-        case 1 * 8 + 2: Q3_MW(1, 2); break;
-        case 1 * 8 + 3: Q3_MW(1, 3); break;
-        case 1 * 8 + 4: Q3_MW(1, 4); break;
-        case 1 * 8 + 5: Q3_MW(1, 5); break;
-        case 2 * 8 + 1: Q3_MW(2, 1); break;
-        case 2 * 8 + 2: Q3_MW(2, 2); break;
-        case 2 * 8 + 3: Q3_MW(2, 3); break;
-        case 2 * 8 + 4: Q3_MW(2, 4); break;
-        case 2 * 8 + 5: Q3_MW(2, 5); break;
-        case 4 * 8 + 1: Q3_MW(4, 1); break;
-        case 4 * 8 + 2: Q3_MW(4, 2); break;
-        case 4 * 8 + 3: Q3_MW(4, 3); break;
-        case 4 * 8 + 4: Q3_MW(4, 4); break;
-        case 4 * 8 + 5: Q3_MW(4, 5); break;
-        case 4 * 8 + 6: Q3_MW(4, 6); break;
-        case 4 * 8 + 7: Q3_MW(4, 7); break;
-        default: Q3_MW(4, 8); break;
-    }
-#undef Q3_MW
+    const MergeWoFn fn = pick_merge_wo<HD>(nj, rw);
+    hipLaunchKernelGGL(fn, grid, blk, 0, st, a, w);
 }
 
 template <int HD, int HPW>
@@ -1299,29 +1363,25 @@ static void launch_attn_wo(const Attn& a, AttMode mode, int rows_cap, int slots,
     wo_geometry(w, n_att, &rpw, &nj, &rw);
     w.rpw = rpw;
     const dim3 grid(n_att + nwo), blk(256);
-#define Q3_AW(NJ, RW) do { if (mode == ATT_SINGLE) hipLaunchKernelGGL((k_attn_wo<HD, HPW, NJ, RW, ATT_SINGLE>), grid, blk, 0, st, a, (int)mode, rows_cap, slots, w); \
-                           else hipLaunchKernelGGL((k_attn_wo<HD, HPW, NJ, RW, ATT_MERGE>), grid, blk, 0, st, a, (int)mode, rows_cap, slots, w); } while (0)
-    switch (nj * 8 + rw) {
-        case 1 * 8 + 1: Q3_AW(1, 1); break;
-        case 1 * 8 + 2: Q3_AW(1, 2); break;
-        case 1 * 8 + 3: Q3_AW(1, 3); break;
-        case 1 * 8 + 4: Q3_AW(1, 4); break;
-        case 2 * 8 + 1: Q3_AW(2, 1); break;
-        case 2 * 8 + 2: Q3_AW(2, 2); break;
-        case 2 * 8 + 3: Q3_AW(2, 3); break;
-        case 2 * 8 + 4: Q3_AW(2, 4); break;
-        case 4 * 8 + 1: Q3_AW(4, 1); break;
-        case 4 * 8 + 2: Q3_AW(4, 2); break;
-        case 4 * 8 + 3: Q3_AW(4, 3); break;
-        case 4 * 8 + 4: Q3_AW(4, 4); break;
-        case 1 * 8 + 5: Q3_AW(1, 5); break;
-        case 2 * 8 + 5: Q3_AW(2, 5); break;
-        case 4 * 8 + 5: Q3_AW(4, 5); break;
-        case 4 * 8 + 6: Q3_AW(4, 6); break;
-        case 4 * 8 + 7: Q3_AW(4, 7); break;
-        default: Q3_AW(4, 8); break;
+    const AttnWoFn fn = pick_attn_wo<HD, HPW>(nj, rw, mode);
+    hipLaunchKernelGGL(fn, grid, blk, 0, st, a, (int)mode, rows_cap, slots, w);
+}
+
+static const void* fused_kernel(const Attn& a, const WoView& w, int chunk_slots, AttMode mode, int* grid, int* rpw_out) {
+    int rpw = 1, nj = 1, rw = 1;
+    const bool two = a.n_heads / a.n_kv > 4;
+    if (mode == ATT_LONG) {
+        const int nm = merge_workgroups(a);
+        wo_geometry(w, nm, &rpw, &nj, &rw);
+        *grid = nm + extra_workgroups(nm);
+        if (rpw_out) *rpw_out = rpw;
+        return (const void*)pick_merge_wo<128>(nj, rw);
     }
-#undef Q3_AW
+    const int n_att = a.n_kv * attn_slots(chunk_slots, mode);
+    wo_geometry(w, n_att, &rpw, &nj, &rw);
+    *grid = n_att + extra_workgroups(n_att);
+    if (rpw_out) *rpw_out = rpw;
+    return two ? (const void*)pick_attn_wo<128, 2>(nj, rw, mode) : (const void*)pick_attn_wo<128, 1>(nj, rw, mode);
 }
 
 void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows_cap, const WoView* wo) {
@@ -1400,7 +1460,7 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows
 __global__ __launch_bounds__(256) void k_begin(const Ctl* ctl, const int8_t* __restrict__ eq,
                                                const float* __restrict__ es, int dim, float* __restrict__ x,
                                                const float* __restrict__ rope, int hd, float* __restrict__ cs,
-                                               unsigned* __restrict__ epoch) {
+                                               unsigned* __restrict__ epoch, int vocab) {
     const int pos = ctl->pos;
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < hd; i += 256) cs[i] = rope[(size_t)pos * hd + i];
@@ -1411,16 +1471,20 @@ __global__ __launch_bounds__(256) void k_begin(const Ctl* ctl, const int8_t* __r
     if (eq) {
         // x = q*s of one embedding row (reference model.c:201-206 dequantises the whole table
         // on the host and forward.c:237 copies a row; the product q*s is the same single rounding)
-        const size_t base = (size_t)ctl->token * dim;
+        // the token may come from device memory (the previous step's argmax or sampler) or, on a pipeline's first stage,
+        // from the slot a neighbour sent: whatever it holds, the row fetched is a row of the table
+        int token = ctl->token;
+        if ((unsigned)token >= (unsigned)vocab) token = 0;
+        const size_t base = (size_t)token * dim;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < dim; i += gridDim.x * 256) {
             x[i] = (float)eq[base + i] * es[(base + i) >> 6];
         }
     }
 }
 void begin_step(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, const float* rope,
-                int hd, float* cs, hipStream_t st, unsigned* epoch) {
+                int hd, float* cs, hipStream_t st, unsigned* epoch, int vocab) {
     const int blocks = eq ? (dim + 255) / 256 : 1;
-    hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(256), 0, st, ctl, eq, es, dim, x, rope, hd, cs, epoch);
+    hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(256), 0, st, ctl, eq, es, dim, x, rope, hd, cs, epoch, vocab);
 }
 
 

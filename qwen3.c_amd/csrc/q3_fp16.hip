@@ -29,12 +29,14 @@ void to_half(const int8_t* q, const float* s, size_t n, void* out, hipStream_t s
     hipLaunchKernelGGL(k_to_half, dim3(4096), dim3(256), 0, st, q, s, n, reinterpret_cast<__half*>(out));
 }
 
-__global__ void k_embed_half(const Ctl* ctl, const __half* __restrict__ e, int dim, float* __restrict__ x) {
-    const size_t base = (size_t)ctl->token * dim;
+__global__ void k_embed_half(const Ctl* ctl, const __half* __restrict__ e, int dim, float* __restrict__ x, int vocab) {
+    int token = ctl->token;                       // may come from device memory: keep it a row of the table (k_begin)
+    if ((unsigned)token >= (unsigned)vocab) token = 0;
+    const size_t base = (size_t)token * dim;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x) x[i] = __half2float(e[base + i]);
 }
-void embed_half(const Ctl* ctl, const void* e, int dim, float* x, hipStream_t st) {
-    hipLaunchKernelGGL(k_embed_half, dim3((dim + 255) / 256), dim3(256), 0, st, ctl, reinterpret_cast<const __half*>(e), dim, x);
+void embed_half(const Ctl* ctl, const void* e, int dim, float* x, hipStream_t st, int vocab) {
+    hipLaunchKernelGGL(k_embed_half, dim3((dim + 255) / 256), dim3(256), 0, st, ctl, reinterpret_cast<const __half*>(e), dim, x, vocab);
 }
 
 // out = W x with the activation (rmsnorm'ed when NORM) staged in LDS as fp32.  One wave per row

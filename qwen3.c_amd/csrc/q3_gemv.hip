@@ -547,7 +547,7 @@ static int maxt_for(int loads) { return loads <= 12 ? 1024 : (loads <= 24 ? 768 
 
 static Plan make_plan(int d, int n, bool pairs, Pro pro) {
     const int NJ = (n + 1023) / 1024, NB = (n + 255) / 256;
-    const int ncu = 256;
+    const int ncu = cu_count();
     const int rows_per_cu = (d + ncu - 1) / ncu;
     const int cand[4] = {1, 2, 4, 8};
     Plan p;

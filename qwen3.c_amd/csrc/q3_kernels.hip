@@ -32,6 +32,21 @@
 
 namespace q3k {
 
+static int g_cu_count = 0;
+void set_cu_count(int n) { if (n > 0) g_cu_count = n; }
+int cu_count() {
+    if (!g_cu_count) {           // (ops called before any Model was attached)
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+            fprintf(stderr, "[q3hip] no device properties\n");
+            exit(EXIT_FAILURE);
+        }
+        g_cu_count = p.multiProcessorCount;
+    }
+    return g_cu_count;
+}
+
 // ---------------------------------------------------------------- GEMV -----
 
 // Activation prologues: leave int8 codes in lq[n] and scales in ls[n/64] (LDS).

@@ -35,6 +35,11 @@ struct Gemv {
     unsigned long long* stamps;
 };
 
+// Compute units of the device the launches go to (set once per process from hipDeviceProp at the first attach; 256 on
+// MI355X).  Launch plans and the fused launches' grids are sized from it.
+void set_cu_count(int n);
+int cu_count();
+
 void gemv(const Gemv& g, Pro pro, Epi epi, hipStream_t st);
 
 struct Attn {
@@ -107,6 +112,7 @@ struct WoView {
     unsigned long long* stamps;   // diagnostic builds only (-DQ3_ATTN_STAMPS): eight device-clock marks per consumer workgroup
     int delay;            // device-clock ticks (10 ns) the extra workgroups hold their weight requests back after entry
     int poll;             // experiments (Q3_WO_POLL): how the consumers wait, see wo_role
+    unsigned long long wait_ticks;   // a consumer gives up after this much device time (10-ns ticks; 5 s unless Q3_WAIT_TICKS says otherwise: tests)
 };
 // rows per consumer workgroup / whether the fused launch covers this shape (else: attn() then gemv())
 bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode);
@@ -118,7 +124,8 @@ void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x,
 // first kernel of a step: x = embedding row of ctl->token (eq may be null on later pipeline
 // stages) and cs = rope[ctl->pos]
 void begin_step(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, const float* rope,
-                int hd, float* cs, hipStream_t st, unsigned* epoch = nullptr);
+                int hd, float* cs, hipStream_t st, unsigned* epoch = nullptr, int vocab = 0x7fffffff);
+// (`vocab`: rows of the embedding table; a token id outside [0, vocab) fetches row 0)
 
 // scratch: 256 words of device memory
 void argmax(const float* logits, int n, float* scratch, int* out, int* out2, hipStream_t st);
@@ -149,7 +156,7 @@ void prefill_begin(const int* tokens, int ntok, int pos0, const int8_t* eq, cons
 
 // ---- fp16 contrast path (q3_fp16.hip; BASELINE config 5) ------------------------------------
 void to_half(const int8_t* q, const float* s, size_t n, void* out, hipStream_t st);     // half(q*s)
-void embed_half(const Ctl* ctl, const void* e, int dim, float* x, hipStream_t st);
+void embed_half(const Ctl* ctl, const void* e, int dim, float* x, hipStream_t st, int vocab = 0x7fffffff);
 // out (=, or += when nw is null) W x, W [d][n] binary16, x fp32 (rmsnorm'ed with weight nw when given);
 // EPI_SWIGLU: rows interleaved (gate, up) -> out[d/2].  Only the three combinations a layer uses exist:
 // (nw, STORE), (nw, SWIGLU), (null, RESID).

@@ -411,19 +411,6 @@ __global__ __launch_bounds__(512) void k_gemm_q8_lds(const int8_t* __restrict__ 
     }
 }
 
-static int cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
-            fprintf(stderr, "[q3hip] gemm_q8: no device properties\n");
-            exit(EXIT_FAILURE);
-        }
-        n = p.multiProcessorCount;
-    }
-    return n;
-}
 
 template <int RT>
 static void launch_gemm_lds(const int8_t* W, const float* S, int n, int d, const int8_t* xq, const float* xs, int ntok,

@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -128,6 +129,12 @@ struct Dev {
     unsigned* epoch = nullptr;    // step counter advanced by k_begin: tags the in-launch hand-offs of k_attn_wo
     unsigned long long* att_g = nullptr;   // attention output as {tag, value} granules [P/4 + P/64] (fused launch)
     unsigned* err_host = nullptr; // host-mapped: [0] set by a consumer whose bounded wait gave up
+    // What has been queued since the last synchronisation that found err_host clear, as closures that queue it again:
+    // when a hand-off inside a fused launch times out, the Model drops to the separate launches (fuse = false, graphs
+    // rebuilt) and the work is redone in this process (sync_checked).
+    std::vector<std::function<void()>> redo;
+    bool replaying = false;
+    int fallbacks = 0;            // how many times that happened (q3_handoff_fallbacks)
     bool fuse = true;             // attention + Wo in one launch below Q3_ATT_LONG cached positions (Q3_FUSE=0: separate launches)
     int pf_delay = 150;           // x 10 ns: how long the consumer workgroups of k_attn_wo hold their Wo requests back (Q3_WO_DELAY)
     unsigned long long* stamps = nullptr;
@@ -349,6 +356,11 @@ Dev* attach(Model* m, const AttachOpts& opt = AttachOpts()) {
     d->logits_host = m->state.logits;
     d->device = pick_device();
     HIPCHK(hipSetDevice(d->device));
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, d->device));
+        q3k::set_cu_count(prop.multiProcessorCount);
+    }
     HIPCHK(hipStreamCreateWithFlags(&d->st, hipStreamNonBlocking));
     d->dim = p->dim; d->hid = p->hidden_dim; d->L = p->n_layers; d->H = p->n_heads;
     d->KV = p->n_kv_heads; d->hd = p->head_dim; d->V = p->vocab_size; d->seq = p->seq_len;
@@ -598,9 +610,12 @@ q3k::WoView wo_view(Dev* d, int l) {
     memset(&w, 0, sizeof(w));
     w.W = L.wo_q; w.S = L.wo_s; w.n = d->P; w.d = d->dim;
     w.x = d->x;
-    w.gran = d->att_g; w.epoch = d->epoch; w.layer_tag = (unsigned)(l & 255) + 1u;
+    // tag = (step counter << 8) | layer_tag: the low byte must hold layer + 1 (a model of 255 layers or more takes the
+    // separate launches: enqueue_layer)
+    w.gran = d->att_g; w.epoch = d->epoch; w.layer_tag = (unsigned)l + 1u;
     w.delay = d->pf_delay;
     { static const int pm = getenv("Q3_WO_POLL") ? atoi(getenv("Q3_WO_POLL")) : 2; w.poll = pm; }
+    { static const unsigned long long wt = getenv("Q3_WAIT_TICKS") ? strtoull(getenv("Q3_WAIT_TICKS"), nullptr, 10) : 500000000ull; w.wait_ticks = wt; }
     w.stamps = d->stamps;
     HIPCHK(hipHostGetDevicePointer((void**)&w.err, d->err_host, 0));
     return w;
@@ -627,7 +642,7 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0, int rows_ca
     {   // head norms + RoPE + cache append + attention + quantise (forward.c:267-291)
         q3k::Attn a = attn_args(d, l, stream);
         bool fused = false;
-        if (d->fuse) {
+        if (d->fuse && l < 255) {
             q3k::WoView w = wo_view(d, l);
             if (mode == q3k::ATT_LONG) w.delay = 0;       // the merge is one round trip long: no reason to hold Wo back
             a.og = d->att_g; a.epoch = d->epoch; a.layer_tag = w.layer_tag;
@@ -697,8 +712,8 @@ void enqueue_step(Dev* d, int pos_shape, int stream = 0) {
     {
         Timed t(d, "begin", 0.0);
         q3k::begin_step(d->ctl, (d->has_embed && !d->fp16) ? d->emb_q : nullptr, d->emb_s, d->dim, d->x, d->rope, d->hd,
-                        d->cs_cur, d->st, d->epoch);
-        if (d->fp16 && d->has_embed) q3k::embed_half(d->ctl, d->emb_h, d->dim, d->x, d->st);
+                        d->cs_cur, d->st, d->epoch, d->V);
+        if (d->fp16 && d->has_embed) q3k::embed_half(d->ctl, d->emb_h, d->dim, d->x, d->st, d->V);
     }
     for (int l = d->l0; l < d->l1; l++) enqueue_layer(d, l, mode, stream, rows_cap);
     if (d->has_cls) enqueue_head(d);
@@ -706,9 +721,39 @@ void enqueue_step(Dev* d, int pos_shape, int stream = 0) {
 
 void launch_stage(Dev* d, int pos, int stream);
 
-// a consumer of an in-launch hand-off that gave up waiting raises err_host[0]: stop loudly, the step's result is void
-void check_handoff(Dev* d) {
-    if (d->err_host && *(volatile unsigned*)d->err_host) Q3_DIE("an in-launch hand-off (attention -> Wo) timed out on the device");
+// A consumer of an in-launch hand-off (k_attn_wo / k_merge_wo) that gave up waiting raises err_host[0]; its step's
+// result is void.  The Model then stops using the fused launches: true = that just happened (the caller redoes its work).
+bool handoff_failed(Dev* d) {
+    if (!d->err_host || !*(volatile unsigned*)d->err_host) return false;
+    if (!d->fuse) Q3_DIE("an in-launch hand-off timed out although the fused launches are off");
+    fprintf(stderr, "[q3hip] an in-launch hand-off (attention -> Wo) timed out on the device: this Model continues with separate launches\n");
+    *(volatile unsigned*)d->err_host = 0;
+    d->fuse = false;
+    d->fallbacks++;
+    for (auto& ex : d->gexec) { if (ex) { HIPCHK(hipGraphExecDestroy(ex)); ex = nullptr; } }
+    for (auto& ex : d->pgexec) { if (ex) { HIPCHK(hipGraphExecDestroy(ex)); ex = nullptr; } }
+    return true;
+}
+// Every synchronisation that hands results to the caller goes through here: wait, and if a hand-off gave up meanwhile,
+// queue everything since the last clean synchronisation again (now unfused) and wait again.
+void wait_step(Dev* d);
+void sync_checked(Dev* d) {
+    wait_step(d);
+    if (handoff_failed(d)) {
+        if (d->world > 1) Q3_DIE("an in-launch hand-off timed out on one stage of a %d-stage pipeline: restart with Q3_FUSE=0", d->world);
+        std::vector<std::function<void()>> jobs;
+        jobs.swap(d->redo);
+        d->replaying = true;
+        for (auto& j : jobs) j();
+        d->replaying = false;
+        HIPCHK(hipStreamSynchronize(d->st));
+        if (handoff_failed(d)) Q3_DIE("hand-off flag raised again after the fallback");
+    }
+    d->redo.clear();
+}
+// remember how to queue a piece of work again (no-op while a replay is running: the jobs run as they are)
+void remember(Dev* d, std::function<void()> job) {
+    if (!d->replaying) d->redo.push_back(std::move(job));
 }
 
 void fetch_logits_async(Dev* d) {
@@ -753,29 +798,27 @@ void wait_step(Dev* d) {
     }
 }
 
-// run one step; logits stay on the device unless `to_host`
-void run_step(Dev* d, int token, int pos, bool to_host) {
-    check_step_args(d, token, pos);
+// Queue one step whose {token, pos} travel as immediate arguments of a one-thread kernel (q3_forward_device): the caller
+// may queue several of these without a sync, so they must not go through the one pinned host slot a later call would
+// overwrite before this step's copy has run.  The step is the graph WITHOUT the ctl upload and without the logits download.
+void enqueue_async_step(Dev* d, int token, int pos) {
     HIPCHK(hipSetDevice(d->device));
-    if (d->world > 1) Q3_DIE("this Model is one stage of a %d-stage pipeline: use q3_pipeline_run()", d->world);
-    if (!to_host) {
-        // Asynchronous step (q3_forward_device): the caller may queue several of these without a sync, so
-        // {token, pos} must not travel through the one pinned host slot a later call would overwrite before
-        // this step's copy has run.  They go as immediate arguments of a one-thread kernel, and the step is
-        // the graph WITHOUT the ctl upload and without the 608-KB logits download.
-        prof_begin(d);
-        q3k::set_ctl(d->ctl, nullptr, token, pos, d->st);
-        launch_stage(d, pos, 0);
-        if (d->tap) {
-            HIPCHK(hipMemcpyAsync(d->tap_host.data(), d->tap_dev, d->tap_host.size() * 4, hipMemcpyDeviceToHost, d->st));
-        }
-        prof_collect(d);
-        return;
+    prof_begin(d);
+    q3k::set_ctl(d->ctl, nullptr, token, pos, d->st);
+    launch_stage(d, pos, 0);
+    if (d->tap) {
+        HIPCHK(hipMemcpyAsync(d->tap_host.data(), d->tap_dev, d->tap_host.size() * 4, hipMemcpyDeviceToHost, d->st));
     }
-    d->ctl_host->token = token;       // synchronous step: the slot is read before this call returns
+    prof_collect(d);
+}
+
+// Queue one synchronous step (forward()): ctl through the pinned slot (read before the call returns), logits downloaded
+// behind it when the host buffer is pinned.
+void enqueue_sync_step(Dev* d, int token, int pos) {
+    HIPCHK(hipSetDevice(d->device));
+    d->ctl_host->token = token;
     d->ctl_host->pos = pos;
-    const bool pinned_ok = d->logits_pinned;
-    if (d->use_graph && !d->prof && !d->tap && pinned_ok) {
+    if (d->use_graph && !d->prof && !d->tap && d->logits_pinned) {
         if (!d->gexec[q3k::step_shape(pos)]) {
             // first step of this Model: capture the launch shapes of the first Q3_ATT_LONG + 1024 positions now, so that
             // no token pays for a graph instantiation when the position crosses into the next shape (beyond that: one
@@ -786,12 +829,7 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
                 d->gexec[k] = build_graph(d, k == mine ? pos : q3k::step_shape_pos(k), true);
             }
         }
-        hipGraphExec_t& ex = d->gexec[q3k::step_shape(pos)];
-        HIPCHK(hipGraphLaunch(ex, d->st));
-        if (to_host) {
-            wait_step(d);
-            check_handoff(d);
-        }
+        HIPCHK(hipGraphLaunch(d->gexec[q3k::step_shape(pos)], d->st));
         return;
     }
     prof_begin(d);
@@ -800,17 +838,23 @@ void run_step(Dev* d, int token, int pos, bool to_host) {
     if (d->tap) {
         HIPCHK(hipMemcpyAsync(d->tap_host.data(), d->tap_dev, d->tap_host.size() * 4, hipMemcpyDeviceToHost, d->st));
     }
-    if (to_host) {
-        if (pinned_ok) {
-            fetch_logits_async(d);
-            wait_step(d);
-        } else {
-            HIPCHK(hipStreamSynchronize(d->st));
-            HIPCHK(hipMemcpy(d->logits_host, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost));
-        }
+    if (d->logits_pinned) fetch_logits_async(d);
+}
+
+// run one step; logits stay on the device unless `to_host`
+void run_step(Dev* d, int token, int pos, bool to_host) {
+    check_step_args(d, token, pos);
+    if (d->world > 1) Q3_DIE("this Model is one stage of a %d-stage pipeline: use q3_pipeline_run()", d->world);
+    if (!to_host) {
+        enqueue_async_step(d, token, pos);
+        remember(d, [d, token, pos] { enqueue_async_step(d, token, pos); });
+        return;
     }
-    prof_collect(d);
-    if (to_host) check_handoff(d);
+    enqueue_sync_step(d, token, pos);
+    remember(d, [d, token, pos] { enqueue_sync_step(d, token, pos); });
+    sync_checked(d);
+    if (!d->logits_pinned) HIPCHK(hipMemcpy(d->logits_host, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost));
+    if (!(d->use_graph && !d->prof && !d->tap && d->logits_pinned)) prof_collect(d);
 }
 
 // ---- context for the stand-alone ops ---------------------------------------
@@ -1036,12 +1080,15 @@ void q3_device_detach(Model* m) {
     destroy_dev(d);
 }
 
+/* how many times this Model fell back from the fused launches to separate ones because an in-launch hand-off timed out */
+int q3_handoff_fallbacks(Model* m) {
+    Dev* d = lookup(m);
+    return d ? d->fallbacks : 0;
+}
+
 void q3_device_sync(Model* m) {
     Dev* d = lookup(m);
-    if (d) {
-        HIPCHK(hipStreamSynchronize(d->st));
-        check_handoff(d);
-    }
+    if (d) sync_checked(d);
 }
 
 float* forward(Model* m, int token, int pos) {
@@ -1058,16 +1105,19 @@ void q3_forward_device(Model* m, int token, int pos) {
 
 void q3_logits_fetch(Model* m) {
     Dev* d = attach(m);
-    HIPCHK(hipStreamSynchronize(d->st));
-    check_handoff(d);
+    sync_checked(d);
     HIPCHK(hipMemcpy(m->state.logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost));
 }
 
 int q3_device_argmax(Model* m) {
     Dev* d = attach(m);
-    q3k::argmax(d->logits, d->V, d->amax_scratch, d->amax, nullptr, d->st);
-    HIPCHK(hipMemcpyAsync(d->amax_host, d->amax, sizeof(int), hipMemcpyDeviceToHost, d->st));
-    HIPCHK(hipStreamSynchronize(d->st));
+    auto pick = [d] {
+        q3k::argmax(d->logits, d->V, d->amax_scratch, d->amax, nullptr, d->st);
+        HIPCHK(hipMemcpyAsync(d->amax_host, d->amax, sizeof(int), hipMemcpyDeviceToHost, d->st));
+    };
+    pick();
+    remember(d, pick);
+    sync_checked(d);
     return *d->amax_host;
 }
 
@@ -1186,6 +1236,17 @@ void pipeline_check(Dev* d, int first_token, int pos0, int nsteps) {
 int pipeline_run(Dev* d, int first_token, int pos0, int nsteps, int streams = 0) {
     pipeline_check(d, first_token, pos0, nsteps);
     if (streams <= 0 || streams > d->world) streams = d->world;
+    if (d->world == 1) {      // (the on-device token loop: redone whole if a hand-off gives up; the sampler's state travels with it)
+        const bool samp = d->samp_on;
+        const float st = d->samp_t, sp = d->samp_p;
+        remember(d, [d, first_token, pos0, nsteps, streams, samp, st, sp] {
+            const bool on = d->samp_on;
+            const float t0 = d->samp_t, p0 = d->samp_p;
+            d->samp_on = samp; d->samp_t = st; d->samp_p = sp;
+            pipeline_run(d, first_token, pos0, nsteps, streams);
+            d->samp_on = on; d->samp_t = t0; d->samp_p = p0;
+        });
+    }
     int ticks = 0;
     const int T = nsteps * d->world + d->world - 1;
     for (int t = 0; t < T; t++) {
@@ -1218,8 +1279,7 @@ int q3_pipeline_tokens(Model* m, int stream, int* out, int n) {
     Dev* d = attach(m);
     if (!d->ptokens || stream < 0 || stream >= d->n_streams) return 0;
     if (n > d->ptokens_cap) n = d->ptokens_cap;
-    HIPCHK(hipStreamSynchronize(d->st));
-    check_handoff(d);
+    sync_checked(d);
     HIPCHK(hipMemcpy(out, d->ptokens + (size_t)stream * d->ptokens_cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     return n;
 }
@@ -1365,17 +1425,24 @@ float* q3_prefill(Model* m, const int* tokens, int n, int pos0) {
     }
     HIPCHK(hipSetDevice(d->device));
     ensure_prefill(d);
-    for (int c0 = 0; c0 < n; c0 += Q3_PF_CHUNK) {
-        const int bc = n - c0 < Q3_PF_CHUNK ? n - c0 : Q3_PF_CHUNK;
-        if (d->fp16) prefill_chunk_f16(d, tokens + c0, bc, pos0 + c0);
-        else prefill_chunk(d, tokens + c0, bc, pos0 + c0);
-        if (c0 + bc < n) HIPCHK(hipStreamSynchronize(d->st));      // the token upload buffer is reused
-    }
-    const int last = (n - 1) % Q3_PF_CHUNK;
-    HIPCHK(hipMemcpyAsync(d->x, d->pf_x + (size_t)last * d->dim, (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
-    enqueue_head(d);
-    HIPCHK(hipMemcpyAsync(m->state.logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost, d->st));
-    HIPCHK(hipStreamSynchronize(d->st));
+    sync_checked(d);                     // steps queued earlier are settled before the passes below wait on the stream
+    float* host_logits = m->state.logits;
+    const std::vector<int> toks(tokens, tokens + n);
+    auto ingest = [d, toks, n, pos0, host_logits] {
+        for (int c0 = 0; c0 < n; c0 += Q3_PF_CHUNK) {
+            const int bc = n - c0 < Q3_PF_CHUNK ? n - c0 : Q3_PF_CHUNK;
+            if (d->fp16) prefill_chunk_f16(d, toks.data() + c0, bc, pos0 + c0);
+            else prefill_chunk(d, toks.data() + c0, bc, pos0 + c0);
+            if (c0 + bc < n) HIPCHK(hipStreamSynchronize(d->st));      // the token upload buffer is reused
+        }
+        const int last = (n - 1) % Q3_PF_CHUNK;
+        HIPCHK(hipMemcpyAsync(d->x, d->pf_x + (size_t)last * d->dim, (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
+        enqueue_head(d);
+        HIPCHK(hipMemcpyAsync(host_logits, d->logits, (size_t)d->V * 4, hipMemcpyDeviceToHost, d->st));
+    };
+    ingest();
+    remember(d, ingest);
+    sync_checked(d);
     return m->state.logits;
 }
 
@@ -1424,9 +1491,13 @@ int q3_device_sample(Model* m, float temperature, float top_p, uint64_t* seed) {
     ensure_sampler(d);
     clamp_sampler(temperature, top_p);
     const float coin = host_xorshift_float(seed);
-    q3k::sample(d->logits, d->V, temperature, top_p, coin, nullptr, d->sb, d->samp_tok, nullptr, d->st);
-    HIPCHK(hipMemcpyAsync(d->samp_tok_host, d->samp_tok, sizeof(int), hipMemcpyDeviceToHost, d->st));
-    HIPCHK(hipStreamSynchronize(d->st));
+    auto draw = [d, temperature, top_p, coin] {
+        q3k::sample(d->logits, d->V, temperature, top_p, coin, nullptr, d->sb, d->samp_tok, nullptr, d->st);
+        HIPCHK(hipMemcpyAsync(d->samp_tok_host, d->samp_tok, sizeof(int), hipMemcpyDeviceToHost, d->st));
+    };
+    draw();
+    remember(d, draw);
+    sync_checked(d);
     return *d->samp_tok_host;
 }
 
@@ -1442,12 +1513,19 @@ int q3_generate_sampled(Model* m, int token, int pos, int n, float temperature, 
     ensure_sampler(d);
     clamp_sampler(temperature, top_p);
     unsigned long long s = *seed;
-    HIPCHK(hipMemcpyAsync(d->seed_dev, &s, sizeof(s), hipMemcpyHostToDevice, d->st));
-    HIPCHK(hipStreamSynchronize(d->st));
+    auto put_seed = [d, s] {
+        unsigned long long v = s;
+        HIPCHK(hipMemcpyAsync(d->seed_dev, &v, sizeof(v), hipMemcpyHostToDevice, d->st));
+        HIPCHK(hipStreamSynchronize(d->st));
+    };
+    sync_checked(d);                     // (what was queued before is settled first: the seed upload below waits on the stream)
+    put_seed();
+    remember(d, put_seed);
     d->samp_on = true; d->samp_t = temperature; d->samp_p = top_p;
     pipeline_run(d, token, pos, n);
     d->samp_on = false;
     if (out_tokens) q3_pipeline_tokens(m, 0, out_tokens, n);
+    sync_checked(d);
     HIPCHK(hipMemcpy(&s, d->seed_dev, sizeof(s), hipMemcpyDeviceToHost));
     *seed = s;
     return n;
@@ -1562,7 +1640,11 @@ void q3_layer_step(Model* m, int layer, int pos, const float* x_in, float* x_out
     HIPCHK(hipMemcpyAsync(d->x, x_in, (size_t)d->dim * 4, hipMemcpyHostToDevice, d->st));
     enqueue_layer(d, layer, q3k::attn_mode(pos), 0, q3k::step_rows_cap(pos));
     HIPCHK(hipStreamSynchronize(d->st));
-    check_handoff(d);
+    if (handoff_failed(d)) {             // redo the one layer with separate launches
+        HIPCHK(hipMemcpyAsync(d->x, x_in, (size_t)d->dim * 4, hipMemcpyHostToDevice, d->st));
+        enqueue_layer(d, layer, q3k::attn_mode(pos), 0, q3k::step_rows_cap(pos));
+        HIPCHK(hipStreamSynchronize(d->st));
+    }
     HIPCHK(hipMemcpy(x_out, d->x, (size_t)d->dim * 4, hipMemcpyDeviceToHost));
     prof_collect(d);
 }
@@ -1619,7 +1701,29 @@ void rmsnorm(float* out, float* x, float* w, int size) {
     dout.to_host(out, st);
 }
 
+// The reference's softmax() reports non-finite values on stderr as it goes (src/forward.c:38-67: "[Softmax] Invalid
+// input" for x[i], i >= 1, in its max loop; "[Softmax] NaN/Inf at" for every exponential that is not finite).  The
+// arithmetic runs on the device; the reports are restated here on the host copy the caller handed in, in the reference's
+// order at one thread, and cost one vectorisable scan when every input is finite (the only case a healthy model
+// produces: an exponential of a finite difference to the maximum cannot be NaN or Inf).
+static void softmax_diagnostics(const float* x, int size) {
+    int bad = 0;
+    for (int i = 0; i < size; i++) bad |= !(fabsf(x[i]) <= 3.402823466e38f);
+    if (!bad) return;
+    float max_val = x[0];
+    for (int i = 1; i < size; i++) {
+        if (std::isnan(x[i]) || std::isinf(x[i])) fprintf(stderr, "[Softmax] Invalid input: x[%d] = %f\n", i, (double)x[i]);
+        if (x[i] > max_val) max_val = x[i];
+    }
+    for (int i = 0; i < size; i++) {
+        const float e = expf(x[i] - max_val);
+        if (std::isnan(e) || std::isinf(e))
+            fprintf(stderr, "[Softmax] NaN/Inf at i=%d: x=%f max_val=%f\n", i, (double)x[i], (double)max_val);
+    }
+}
+
 void softmax(float* x, int size) {
+    softmax_diagnostics(x, size);
     hipStream_t st = ops_stream();
     DBuf dx(x, (size_t)size * 4);
     q3k::softmax(dx.as<float>(), size, st);

@@ -167,6 +167,8 @@ def hip_lib():
         lib.q3_forward_device.argtypes = [ModelP, C.c_int, C.c_int]
         lib.q3_logits_fetch.restype = None
         lib.q3_logits_fetch.argtypes = [ModelP]
+        lib.q3_handoff_fallbacks.restype = C.c_int
+        lib.q3_handoff_fallbacks.argtypes = [ModelP]
         lib.q3_device_argmax.restype = C.c_int
         lib.q3_device_argmax.argtypes = [ModelP]
         lib.q3_generate_greedy.restype = C.c_int

@@ -340,3 +340,44 @@ def test_fused_attention_wo_launch_equals_separate_launches(hip, name):
         assert np.array_equal(a, b), (name, pos)
         tok = int(a.argmax())
     hip.q3_model_close(ma); hip.q3_model_close(mb)
+
+
+def _nan_checkpoint(name):
+    """A synthetic checkpoint whose final RMSNorm weights are NaN: every logit of every step is NaN."""
+    import shutil, struct
+    src = os.path.join(Q.tmp_dir(), f"{name}.bin")
+    spec = Q.synth(name, src)
+    dst = os.path.join(Q.tmp_dir(), f"{name}_nan_out_norm.bin")
+    shutil.copyfile(src, dst)
+    # layout (q3_model.c): 256-byte header, att_rms_norm[L][dim], ffn_rms_norm[L][dim], out_rms_norm[dim], ...
+    off = 256 + 2 * spec.n_layers * spec.dim * 4
+    with open(dst, "r+b") as f:
+        f.seek(off)
+        f.write(struct.pack("<f", float("nan")) * spec.dim)
+    return dst, spec
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_nan_logits_never_become_an_out_of_range_token_on_the_device(hip, fp16):
+    """Round-3 GPU fault, regression: all-NaN logits made the device argmax return its INT_MAX sentinel, and the next
+    step's k_begin fetched embedding row INT_MAX * dim.  The argmax now yields a valid id, and k_begin bounds whatever
+    token id device memory hands it."""
+    import ctypes as C
+    path, spec = _nan_checkpoint("small")
+    m = hip.q3_model_open(path.encode(), 0, 0)
+    if fp16:
+        assert hip.q3_device_attach_fp16(m) == 0
+    lg = Q.logits_array(m, hip.forward(m, 5, 0))
+    assert np.isnan(lg).all()
+    assert 0 <= hip.q3_argmax(hip.forward(m, 5, 0), spec.vocab_size) < spec.vocab_size          # host argmax
+    hip.q3_forward_device(m, 7, 1)
+    t = hip.q3_device_argmax(m)                                                                  # device argmax
+    assert 0 <= t < spec.vocab_size, t
+    out = (C.c_int * 3)()
+    assert hip.q3_generate_greedy(m, 9, 2, 3, out) == 3                                          # the loop feeds its own picks back
+    assert all(0 <= out[i] < spec.vocab_size for i in range(3)), list(out)
+    seed = C.c_uint64(1)
+    out2 = (C.c_int * 3)()
+    hip.q3_generate_sampled(m, 9, 5, 3, C.c_float(0.8), C.c_float(0.9), C.byref(seed), out2)   # NaN probabilities: any valid id
+    assert all(0 <= out2[i] < spec.vocab_size for i in range(3)), list(out2)
+    hip.q3_model_close(m)

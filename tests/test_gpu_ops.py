@@ -5,6 +5,7 @@ Bars: q8_quantize bit-exact with the reference order; every other op bit-exact w
 oracle's tree order (ORC_TREE restates the device reduction trees) AND within 1e-6 of
 max|out| of the reference order (ORC_REF, pinned to the real reference)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -196,3 +197,62 @@ def test_dequantize(hip):
     t = Q.q8view(q, s)
     hip.q8_dequantize(C.byref(t), Q.fptr(out), n, 64)
     assert np.array_equal(out, q.astype(np.float32) * np.repeat(s, 64))
+
+
+def _capture_stderr(fn):
+    """Run fn() with file descriptor 2 redirected to a temporary file (C-level fprintf included); return the text."""
+    import os, sys, tempfile
+    sys.stderr.flush()
+    saved = os.dup(2)
+    with tempfile.TemporaryFile(mode="w+b") as tf:
+        os.dup2(tf.fileno(), 2)
+        try:
+            fn()
+        finally:
+            os.dup2(saved, 2)
+            os.close(saved)
+        tf.seek(0)
+        return tf.read().decode()
+
+
+@pytest.mark.parametrize("case", ["nan_first", "nan_mid", "plus_inf", "minus_inf", "finite"])
+def test_softmax_export_keeps_the_reference_diagnostics(hip, orc, case):
+    """The exported softmax() (host pointer in and out, arithmetic on the device) reports non-finite values the way
+    the reference's does (src/forward.c:38-67) and leaves the same values behind: all NaN once a NaN or +Inf is in,
+    exact zeros for -Inf."""
+    rng = np.random.default_rng(3)
+    n = 5000
+    x = (rng.standard_normal(n) * 3).astype(np.float32)
+    if case == "nan_first": x[0] = np.nan
+    if case == "nan_mid": x[1234] = np.nan
+    if case == "plus_inf": x[77] = np.inf
+    if case == "minus_inf": x[3] = -np.inf; x[4000] = -np.inf
+    got = x.copy()
+    text = _capture_stderr(lambda: hip.softmax(Q.fptr(got), n))
+    ref = Q.reference_lib()
+    if ref is not None:                       # the reference itself, built here from /root/reference (1 thread: its order)
+        exp = x.copy()
+        ref.softmax.restype = None
+        ref.softmax.argtypes = [Q.c_float_p, C.c_int]
+        rtext = _capture_stderr(lambda: ref.softmax(Q.fptr(exp), n))
+        assert sorted(text.splitlines()) == sorted(rtext.splitlines())
+        if os.environ.get("OMP_NUM_THREADS", "1") == "1":
+            assert text == rtext
+    else:
+        orc.orc_set_mode(Q.ORC_REF)
+        exp = x.copy()
+        orc.orc_softmax(Q.fptr(exp), n)
+    if case == "finite":
+        assert text == ""
+    if case == "nan_mid":
+        assert "[Softmax] Invalid input: x[1234] = nan" in text and "[Softmax] NaN/Inf at i=1234: x=nan" in text
+    if case == "nan_first":
+        assert "Invalid input" not in text and text.count("[Softmax] NaN/Inf at i=") == n     # the reference never looks at x[0] in its first loop
+    if case == "minus_inf":
+        assert "[Softmax] Invalid input: x[3] = -inf" in text and "NaN/Inf at" not in text
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    if ok.any():
+        # (fp32 sums in different orders: the device tree, the reference sequential or split over its OpenMP threads)
+        assert float(np.abs(got[ok] - exp[ok]).max()) <= 5e-6 * float(np.abs(exp[ok]).max())
+        assert np.array_equal(got[ok] == 0.0, exp[ok] == 0.0)
