@@ -110,11 +110,20 @@ def chain_floor_from_log(path):
 
 def job_nonce():
     """8 bytes that every rank of THIS job agrees on and another job does not share: the launcher's run id
-    (torch.distributed.run exports TORCHELASTIC_RUN_ID to every worker; spawn_ranks exports Q3_JOB_NONCE), hashed.
-    Without either (a hand-rolled launcher) the tag is the same for every job and only the mtime window and
-    rank 0's unlink after the rendezvous keep an old file out."""
+    (spawn_ranks exports Q3_JOB_NONCE; torch.distributed.run exports TORCHELASTIC_RUN_ID to every worker -- but a
+    default standalone run has the constant id "none", so then, and without either, the tag is built from the
+    launcher's pid and start time, which the ranks of one launch share), hashed."""
     import hashlib
     key = os.environ.get("Q3_JOB_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    if key in ("", "none"):
+        # a default standalone torch.distributed.run exports the constant run id "none": fall back to what the ranks of one
+        # launch share and another launch does not -- the launcher (their common parent process) and its start time
+        ppid = os.getppid()
+        try:
+            started = open(f"/proc/{ppid}/stat").read().rsplit(")", 1)[1].split()[19]      # field 22: starttime
+        except (OSError, IndexError):
+            started = ""
+        key = f"{os.environ.get('MASTER_PORT', '')}:{ppid}:{started}"
     return hashlib.sha256(key.encode()).digest()[:8]
 
 
@@ -266,6 +275,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 512 / 4096 cached-position points")
     ap.add_argument("--no-dropin", action="store_true", help="skip the reference-loader + host-sampler loop")
+    ap.add_argument("--no-models", action="store_true", help="skip the 1.7B / 8B points of the default line")
     args = ap.parse_args()
 
     os.environ["OMP_NUM_THREADS"] = str(host_cores())   # before libgomp is first loaded
@@ -493,10 +503,13 @@ def main():
         copy = hip.q3_measure_copy_gbps(1 << 30, 8)
         out["hbm_copy_gbps_measured"] = round(copy, 1)
         if args.model == "4B":
-            # context for `value`: what the platform charges for this step's 182 dependent launches when every launch
-            # only streams its stage's bytes (tools/micro/chain_floor.hip) -- a committed measurement, not re-run here
-            floor = chain_floor_from_log(os.path.join(ROOT, "profiles", "r02_chain_floor.log"))      # (five launches per layer; the step now has four)
+            # context for `value`: what the platform charges for this step's 146 dependent launches (four per layer) when
+            # every launch only streams its stage's bytes (tools/micro/chain_floor.hip) -- a committed measurement of
+            # round 4, not re-run here
+            floor = chain_floor_from_log(os.path.join(ROOT, "profiles", "r04_chain_floor.log"))
             if floor:
+                floor["launches_per_token"] = 146
+                floor["launches_per_layer"] = 4
                 out["dependent_launch_floor"] = floor
         out["frac_of_measured_copy"] = round(per_gpu_rate * bpt / 1e9 / copy, 4)
         hip.q3_prof_enable(m, 1)
@@ -551,6 +564,34 @@ def main():
                                "us_per_launch": us_best}
         out["kernels"] = kern
     hip.q3_model_close(m)
+
+    if rank == 0 and ngpu == 1 and args.model == "4B" and args.dtype == "q8" and not args.no_models:
+        # BASELINE configs 2 and 4 in the driver-visible line: the same decode loop on the 1.7B shapes and on the 8B
+        # shapes (untied classifier), 64 steps each after 8 untimed ones, one GPU; `value` stays the 4B figure
+        models = {}
+        for name in ("1.7B", "8B"):
+            try:
+                mp = os.path.join(tmp, f"{name}.bin")
+                Q.synth(name, mp)
+                mm = hip.q3_model_open(mp.encode(), 1024, 0)
+                pp = mm.contents.params
+                vv = pp.vocab_size
+                t_tok, t_pos = START_TOKEN % vv, 0
+                for _ in range(8):
+                    t_tok = hip.q3_argmax(hip.forward(mm, t_tok, t_pos), vv); t_pos += 1
+                hip.q3_device_sync(mm)
+                t1 = time.perf_counter()
+                for _ in range(64):
+                    t_tok = hip.q3_argmax(hip.forward(mm, t_tok, t_pos), vv); t_pos += 1
+                hip.q3_device_sync(mm)
+                rate = 64 / (time.perf_counter() - t1)
+                b_m = hip.q3_bytes_per_token(C.byref(pp), 8 + 32)
+                models[name] = {"tokens_per_s": round(rate, 2), "frac_of_hbm_roofline": round(rate * b_m / 1e9 / HBM_PEAK_GBS, 4),
+                                "bytes_per_token": int(b_m), "steps": 64, "warmup": 8}
+                hip.q3_model_close(mm)
+            except Exception as exc:      # a reported extra, never a reason to lose the line
+                models[name] = {"error": repr(exc)}
+        out["models"] = models
 
     if rank == 0 and ngpu == 1 and not args.no_cpu_baseline:
         try:

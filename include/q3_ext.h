@@ -60,6 +60,10 @@ int q3_synth_preset(const char* name, Q3SynthSpec* spec);
 int q3_synth_write(const char* path, const Q3SynthSpec* spec);
 /* Bytes q3_synth_write will produce for `spec`. */
 int64_t q3_synth_bytes(const Q3SynthSpec* spec);
+/* Write "<model_path>.tokenizer" in the reference's tokenizer format (src/tokenizer.c:17-120): single bytes, a few
+ * merges, Qwen's special strings at the end of the vocabulary, printable fillers elsewhere -- what the reference's
+ * qwen_create() / completion() need next to a synthetic checkpoint.  Returns 0 on success. */
+int q3_synth_write_tokenizer(const char* model_path, int vocab_size);
 /* 64-bit FNV-1a of a file, for fixture checksums. */
 uint64_t q3_file_checksum(const char* path);
 

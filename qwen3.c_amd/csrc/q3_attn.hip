@@ -1429,9 +1429,9 @@ void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows
     dim3 grid(a.n_kv, slots, nz);
     static const bool long_loader = !(getenv("Q3_ATT_LOADER") && getenv("Q3_ATT_LOADER")[0] == '0');
     if (mode == ATT_LONG && long_loader && a.hd == 128) {      // (head_dim 64: the one-role kernel; its general path does not fit 128 registers)
-        // chunk slots that hold cached positions for certain
-        // (16 per 1024 positions the shape has reached for certain: step_rows_cap; the op-level hook and every caller
-        // that does not say get 16 -- attn_mode() sent them here, so at least 1024 positions are cached)
+        // chunk slots that hold cached positions for certain: what the caller vouches for (step_rows_cap: 16 per 1024
+        // positions the launch shape has reached), never fewer than the 16 the mode itself implies (attn_mode() sent the
+        // caller here, so at least Q3_ATT_LONG positions are cached); a caller that does not say (rows_cap 0) gets those 16
         int sure = rows_cap < Q3_ATT_LONG / Q3_ATT_CHUNK ? Q3_ATT_LONG / Q3_ATT_CHUNK : rows_cap;
         if (sure > slots) sure = slots;
         if (!two) hipLaunchKernelGGL((k_attn_long<128, 1>), grid, dim3(512), 0, st, a, sure);

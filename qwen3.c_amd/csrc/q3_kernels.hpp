@@ -116,9 +116,10 @@ struct WoView {
 };
 // rows per consumer workgroup / whether the fused launch covers this shape (else: attn() then gemv())
 bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode);
-// `rows_cap`: see step_rows_cap (one-chunk shapes: tile rows; ATT_LONG: chunk slots certain to exist, 16 when in doubt).  `wo` non-null: Wo rides along -- with the attention launch
+// `rows_cap`: see step_rows_cap (one-chunk shapes: tile rows; ATT_LONG: chunk slots certain to exist); 0 = not said: whole
+// tiles, and in ATT_LONG the 16 slots that the mode itself implies (at least Q3_ATT_LONG positions are cached).  `wo` non-null: Wo rides along -- with the attention launch
 // (ATT_SINGLE / ATT_MERGE: k_attn_wo) or with the merge launch (ATT_LONG: k_merge_wo).
-void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows_cap = 64, const WoView* wo = nullptr);
+void attn(const Attn& a, int chunk_slots, AttMode mode, hipStream_t st, int rows_cap = 0, const WoView* wo = nullptr);
 
 void embed(const Ctl* ctl, const int8_t* eq, const float* es, int dim, float* x, hipStream_t st);
 // first kernel of a step: x = embedding row of ctl->token (eq may be null on later pipeline

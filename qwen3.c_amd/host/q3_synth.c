@@ -282,6 +282,58 @@ int q3_synth_write(const char* path, const Q3SynthSpec* sp) {
     return err ? -1 : 0;
 }
 
+/* ---- synthetic tokenizer (.bin.tokenizer, version 2) ---------------------------------------------------
+ * The reference's qwen_create() opens "<model path>.tokenizer" next to the checkpoint (src/qwen.c:14-49,
+ * src/tokenizer.c:17-120; written by its exporter qwen3/tokenizer.py).  Layout, little endian:
+ *   u32 magic "qtkn" 0x71746B6E | i32 version 2 | i32 vocab_size | i32 max_len | 10 x i32 special ids
+ *   (bos eos eot pad bor eor btc etc btr etr) | per token: f32 score, i32 length, `length` bytes.
+ * What is written: ids 1..255 the single bytes (id 0: a placeholder no input matches), a few merges so that the
+ * reference's byte-pair loop has work to do, Qwen's nine special strings at the END of the vocabulary, and
+ * unique printable fillers "[tNNNNNN]" everywhere else -- every id of a model's vocabulary decodes to text.
+ * Same vocab_size => same bytes. */
+static int tok_put(FILE* f, float score, const char* s, int len) {
+    return fwrite(&score, 4, 1, f) == 1 && fwrite(&len, 4, 1, f) == 1 && (len == 0 || fwrite(s, 1, (size_t)len, f) == (size_t)len);
+}
+int q3_synth_write_tokenizer(const char* model_path, int vocab_size) {
+    static const char* merges[] = {"he", "ll", "lo", "hello", " w", "or", "ld", " wor", " world", "th", "the", " the", "in", "er", "an", " a"};
+    static const char* specials[] = {"<|endoftext|>", "<|im_end|>", "<|im_start|>", "<think>", "</think>", "<tool_call>", "</tool_call>",
+                                     "<tool_response>", "</tool_response>"};
+    const int n_merges = (int)(sizeof(merges) / sizeof(merges[0])), n_spec = (int)(sizeof(specials) / sizeof(specials[0]));
+    if (!model_path || vocab_size < 256 + n_merges + n_spec) return -1;
+    char* path = (char*)malloc(strlen(model_path) + 16);
+    if (!path) return -1;
+    sprintf(path, "%s.tokenizer", model_path);
+    FILE* f = fopen(path, "wb");
+    free(path);
+    if (!f) return -1;
+    const int spec0 = vocab_size - n_spec;               /* first special id */
+    const uint32_t magic = 0x71746B6Eu;
+    const int32_t head[3] = {2, vocab_size, 32};
+    /* bos eos eot pad | bor eor | btc etc | btr etr   (pad = bos, as in Qwen's files) */
+    const int32_t special[10] = {spec0, spec0 + 1, spec0 + 2, spec0, spec0 + 3, spec0 + 4, spec0 + 5, spec0 + 6, spec0 + 7, spec0 + 8};
+    int ok = fwrite(&magic, 4, 1, f) == 1 && fwrite(head, 4, 3, f) == 3 && fwrite(special, 4, 10, f) == 10;
+    for (int id = 0; ok && id < vocab_size; id++) {
+        char buf[32];
+        if (id == 0) {
+            ok = tok_put(f, -1e9f, "[nul]", 5);
+        } else if (id < 256) {
+            buf[0] = (char)id;
+            ok = tok_put(f, -1e6f, buf, 1);
+        } else if (id < 256 + n_merges) {
+            const char* m = merges[id - 256];
+            ok = tok_put(f, (float)(n_merges - (id - 256)) + (float)strlen(m), m, (int)strlen(m));     /* longer merges win */
+        } else if (id >= spec0) {
+            const char* m = specials[id - spec0];
+            ok = tok_put(f, 0.0f, m, (int)strlen(m));
+        } else {
+            const int n = snprintf(buf, sizeof(buf), "[t%06d]", id);
+            ok = tok_put(f, -1e9f, buf, n);
+        }
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 0 : -1;
+}
+
 uint64_t q3_file_checksum(const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) return 0;

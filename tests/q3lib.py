@@ -91,6 +91,8 @@ def _bind_host(lib):
     lib.q3_synth_preset.argtypes = [C.c_char_p, C.POINTER(SynthSpec)]
     lib.q3_synth_write.restype = C.c_int
     lib.q3_synth_write.argtypes = [C.c_char_p, C.POINTER(SynthSpec)]
+    lib.q3_synth_write_tokenizer.restype = C.c_int
+    lib.q3_synth_write_tokenizer.argtypes = [C.c_char_p, C.c_int]
     lib.q3_synth_bytes.restype = C.c_int64
     lib.q3_synth_bytes.argtypes = [C.POINTER(SynthSpec)]
     lib.q3_file_checksum.restype = C.c_uint64

@@ -102,3 +102,82 @@ def test_reference_loop_flat_distributions_teacher_forced(hip, name, vocab, n, t
     diff = [k for k in range(n) if got[k] != want[k]]
     Q.record_parity(f"dropin_loop_{name}_T{temperature}_p{top_p}", {"steps": n, "differing_choices": len(diff), "final_seed_equal": True})
     assert len(diff) <= n // 3, diff
+
+
+class QwenConfig(C.Structure):
+    """reference include/qwen.h:65-72"""
+    _fields_ = [("path", C.c_char_p), ("think", C.c_int), ("seed", C.c_uint64), ("temperature", C.c_float),
+                ("top_p", C.c_float), ("seq_len", C.c_int)]
+
+
+def _capture_stdout(fn):
+    """fn() with file descriptor 1 redirected to a temporary file; the C library's stdout buffer is flushed before
+    and after (completion() ends with an unflushed newline)."""
+    import sys, tempfile
+    libc = C.CDLL(None)
+    sys.stdout.flush(); libc.fflush(None)
+    saved = os.dup(1)
+    with tempfile.TemporaryFile(mode="w+b") as tf:
+        os.dup2(tf.fileno(), 1)
+        try:
+            fn()
+        finally:
+            libc.fflush(None)
+            os.dup2(saved, 1)
+            os.close(saved)
+        tf.seek(0)
+        return tf.read()
+
+
+def _complete(lib, path, prompt, seq_len, temperature, top_p, seed):
+    """qwen_create() + completion() + qwen_free() of `lib`, as examples/qwen.c drives them (src/qwen.c:14-49,
+    src/completion.c:24-84); returns what completion() printed."""
+    lib.qwen_create.restype = C.c_void_p
+    lib.qwen_create.argtypes = [C.POINTER(QwenConfig)]
+    lib.completion.restype = None
+    lib.completion.argtypes = [C.c_void_p, C.c_char_p]
+    lib.qwen_free.restype = None
+    lib.qwen_free.argtypes = [C.c_void_p]
+    cfg = QwenConfig(path.encode(), 1, seed, temperature, top_p, seq_len)
+    q = lib.qwen_create(C.byref(cfg))
+    assert q, "qwen_create failed"
+    buf = C.create_string_buffer(prompt.encode())
+    out = _capture_stdout(lambda: lib.completion(q, buf))
+    return q, out
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+@pytest.mark.parametrize("prompt", ["hello world", "the <think> in a<|im_start|>an"])
+def test_reference_completion_runs_through_the_dropin(hip, host, name, prompt):
+    """north_star: "keeps the reference's forward()/generate() call surface".  The reference's OWN generate path --
+    qwen_create() (its tokenizer loader, its model loader, its sampler) and completion() (its byte-pair encoder, its
+    forward()+sample() loop, its printf) -- executed from the library that has libq3hip.so in place of src/forward.c and
+    src/q8.c, against the same call on the all-reference build at one thread, in the reference's "-t 0 -s 1" setting:
+    the text printed must be the same, byte for byte.  The tokenizer file next to the synthetic checkpoint comes from
+    q3_synth_write_tokenizer (format: src/tokenizer.c:43-109)."""
+    ref, drop = Q.reference_lib(), Q.dropin_lib()
+    if ref is None or drop is None:
+        pytest.skip("oracle/_ref not available")
+    gomp = C.CDLL("libgomp.so.1")
+    gomp.omp_set_num_threads(1)
+    path = os.path.join(Q.tmp_dir(), f"{name}.bin")
+    spec = Q.synth(name, path)
+    assert host.q3_synth_write_tokenizer(path.encode(), spec.vocab_size) == 0
+    seq = min(48, spec.seq_len)
+    qr, want = _complete(ref, path, prompt, seq, 0.0, 0.9, 1)
+    ref.qwen_free(qr)
+    qd, got = _complete(drop, path, prompt, seq, 0.0, 0.9, 1)
+    # (the GPU state hangs off the Model inside the Qwen: first field, include/qwen.h:92-97)
+    hip.q3_device_detach(C.cast(C.cast(qd, C.POINTER(C.c_void_p))[0], Q.ModelP))
+    drop.qwen_free(qd)
+    assert len(want) > len(prompt) and want.endswith(b"\n")
+    assert got == want
+    # ... and a sampled run against the CPU twin (the same reference code around the oracle's tree-order forward):
+    # identical logits bit for bit, so the same text for any temperature
+    twin = Q.dropin_lib(twin=True)
+    qt, want2 = _complete(twin, path, prompt, seq, 0.8, 0.95, 7)
+    twin.qwen_free(qt)
+    qd, got2 = _complete(drop, path, prompt, seq, 0.8, 0.95, 7)
+    hip.q3_device_detach(C.cast(C.cast(qd, C.POINTER(C.c_void_p))[0], Q.ModelP))
+    drop.qwen_free(qd)
+    assert got2 == want2
