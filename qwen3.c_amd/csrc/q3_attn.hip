@@ -691,7 +691,9 @@ __device__ __forceinline__ void hold_back(int ticks) {
 #else
 #define WSTAMP(i) do {} while (0)
 #endif
-template <int NJ, int RW>
+// NWV = waves of the consumer workgroup (4: k_merge_wo; 8: k_attn_wo, whose attention workgroups leave four of their eight
+// waves at once -- twice the waves halve a consumer's rows per wave, i.e. the dot products behind the hand-off)
+template <int NJ, int RW, int NWV = 4>
 __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, float* ls, int* flag) {
     const int tid = threadIdx.x, lane = tid & 63;
     WSTAMP(0);
@@ -729,7 +731,8 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
     // scale g.  Thread t owns code granules t, t + 256, ... and (t < n/64) one scale granule.  A wave first re-reads
     // only its lanes' FIRST granule (a few lines per poll, so that 256 waiting workgroups do not load the fabric the
     // attention chain's own round trips go through), then sweeps the rest until every tag matches.  Bounded.
-    constexpr int NG = NJ;                       // code granules per thread: (n/4) / 256 <= NJ
+    constexpr int NT = 64 * NWV;
+    constexpr int NG = (NJ * 256 + NT - 1) / NT;   // code granules per thread: (n/4) / NT, n <= 1024 NJ
     const int ncode = n >> 2, nscale = n >> 6;
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     const g_u64* gr = (const g_u64*)w.gran;
@@ -762,7 +765,7 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
             unsigned long long x[NG];
 #pragma unroll
             for (int k = 0; k < NG; k++) {
-                const int i = tid + 256 * k;
+                const int i = tid + NT * k;
                 x[k] = __hip_atomic_load(gr + (i < ncode ? i : ncode - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const unsigned long long xs = __hip_atomic_load(gr + ncode + (tid < nscale ? tid : nscale - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -779,7 +782,7 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
     }
 #pragma unroll
     for (int k = 0; k < NG; k++) {
-        const int i = tid + 256 * k;
+        const int i = tid + NT * k;
         if (i < ncode) reinterpret_cast<unsigned*>(lq)[i] = val[k];
     }
     if (tid < nscale) ls[tid] = __uint_as_float(sval);
@@ -803,19 +806,20 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
 }
 
 template <int HD, int HPW, int NJ, int RW, int MODE>
-__global__ __launch_bounds__(256, 2) void k_attn_wo(Attn a, int multi, int rows_cap, int nslots, WoView w) {
+__global__ __launch_bounds__(512) void k_attn_wo(Attn a, int multi, int rows_cap, int nslots, WoView w) {
     __shared__ __attribute__((aligned(16))) float Ks[Q3_ATT_CHUNK * HD];
     __shared__ __attribute__((aligned(16))) float Vs[Q3_ATT_CHUNK * HD];
     __shared__ int last_flag;
     const int n_att = a.n_kv * nslots;
     const int b = blockIdx.x;
     if (b < n_att) {
+        if (threadIdx.x >= 256) return;        // the attention body is a four-wave program: the other four waves leave at once
         const bool fin = attn_body<HD, HPW, true, 0, MODE>(a, multi, MODE == ATT_SINGLE ? b : b % a.n_kv, MODE == ATT_SINGLE ? 0 : b / a.n_kv,
                                                            MODE == ATT_SINGLE ? 1 : nslots, rows_cap, Ks, Vs, &last_flag);
         (void)fin;      // its granules are the publication: nothing to drain, no flag to raise
         return;
     }
-    wo_role<NJ, RW>(w, b - n_att, reinterpret_cast<int8_t*>(Ks), Vs, &last_flag);
+    wo_role<NJ, RW, 8>(w, b - n_att, reinterpret_cast<int8_t*>(Ks), Vs, &last_flag);
 }
 
 // ---- batched prompt ingestion: zb consecutive positions share ONE staged K/V tile --------------
@@ -1238,12 +1242,12 @@ void kv_append(const Attn& a, int ntok, hipStream_t st) {
 // workgroup of the grid being resident at once)
 static int extra_workgroups(int n_att) { const int ncu = cu_count(); return n_att < ncu * 3 / 4 ? ncu - n_att : ncu / 4; }
 static int merge_workgroups(const Attn& a);
-static bool wo_geometry(const WoView& w, int n_att, int* rpw, int* nj, int* rw) {
+static bool wo_geometry(const WoView& w, int n_att, int* rpw, int* nj, int* rw, int nwv = 4) {
     if (w.n % 64 || w.n > 4096 || w.d < 1) return false;
     const int nwo = extra_workgroups(n_att);
     *rpw = (w.d + nwo - 1) / nwo;
     *nj = (w.n + 1023) / 1024;
-    *rw = (*rpw + 3) / 4;
+    *rw = (*rpw + nwv - 1) / nwv;
     // (up to 8 rows of 4 KiB per wave = 160 registers of tile: the 8B shapes' in-launch-merge launch, 32 rows per consumer)
     return (*nj == 1 || *nj == 2 || *nj == 4) && (*rw <= 5 || (*nj == 4 && *rw <= 8));
 }
@@ -1254,17 +1258,17 @@ static int attn_slots(int chunk_slots, AttMode mode) {
     return mode == ATT_SINGLE ? 1 : (mode == ATT_MERGE ? merge_slots : chunk_slots);
 }
 static const void* fused_kernel(const Attn& a, const WoView& w, int chunk_slots, AttMode mode, int* grid, int* rpw_out);
-static bool grid_resident(const void* kernel, int grid);
+static bool grid_resident(const void* kernel, int grid, int threads);
 bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode mode) {
     int rpw, nj, rw;
     // (head_dim 128 only -- every Qwen3 size; the head_dim-64 test shapes take the separate launches)
     if (!(a.nz <= 1 && !a.of && !a.prepared && a.n_heads / a.n_kv <= Q3_MAXG && a.hd == 128)) return false;
     if (!w.W || !a.og || !a.epoch) return false;
     const int producers = mode == ATT_LONG ? merge_workgroups(a) : a.n_kv * attn_slots(chunk_slots, mode);
-    if (!(w.n == a.n_heads * a.hd && w.n <= 4096 && producers < cu_count() && wo_geometry(w, producers, &rpw, &nj, &rw))) return false;
+    if (!(w.n == a.n_heads * a.hd && w.n <= 4096 && producers < cu_count() && wo_geometry(w, producers, &rpw, &nj, &rw, mode == ATT_LONG ? 4 : 8))) return false;
     int grid = 0;
     const void* kern = fused_kernel(a, w, chunk_slots, mode, &grid, nullptr);
-    if (!grid_resident(kern, grid)) {
+    if (!grid_resident(kern, grid, mode == ATT_LONG ? 256 : 512)) {
         static bool told = false;
         if (!told) fprintf(stderr, "[q3hip] the fused attention + Wo launch (%d workgroups) would not be resident at once on this device: separate launches\n", grid);
         told = true;
@@ -1330,7 +1334,7 @@ static AttnWoFn pick_attn_wo(int nj, int rw, AttMode mode) {
 // every workgroup of the grid holds a CU at once.  Checked per kernel against the runtime's occupancy answer (cached);
 // one workgroup per CU is all these grids ask for, so a grid of at most cu_count() workgroups is resident when the
 // answer is at least 1.  The bounded waits and the host's fallback (q3_shim.hip: sync_checked) stay as the backstop.
-static bool grid_resident(const void* kernel, int grid) {
+static bool grid_resident(const void* kernel, int grid, int threads) {
     static std::unordered_map<const void*, int> cache;
     auto it = cache.find(kernel);
     int per_cu;
@@ -1338,7 +1342,7 @@ static bool grid_resident(const void* kernel, int grid) {
         per_cu = it->second;
     } else {
         per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess) per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) per_cu = 0;
         cache[kernel] = per_cu;
     }
     return per_cu >= 1 && grid <= per_cu * cu_count();
@@ -1360,9 +1364,9 @@ template <int HD, int HPW>
 static void launch_attn_wo(const Attn& a, AttMode mode, int rows_cap, int slots, WoView w, hipStream_t st) {
     int rpw = 1, nj = 1, rw = 1;
     const int n_att = a.n_kv * slots, nwo = extra_workgroups(n_att);
-    wo_geometry(w, n_att, &rpw, &nj, &rw);
+    wo_geometry(w, n_att, &rpw, &nj, &rw, 8);
     w.rpw = rpw;
-    const dim3 grid(n_att + nwo), blk(256);
+    const dim3 grid(n_att + nwo), blk(512);
     const AttnWoFn fn = pick_attn_wo<HD, HPW>(nj, rw, mode);
     hipLaunchKernelGGL(fn, grid, blk, 0, st, a, (int)mode, rows_cap, slots, w);
 }
@@ -1378,7 +1382,7 @@ static const void* fused_kernel(const Attn& a, const WoView& w, int chunk_slots,
         return (const void*)pick_merge_wo<128>(nj, rw);
     }
     const int n_att = a.n_kv * attn_slots(chunk_slots, mode);
-    wo_geometry(w, n_att, &rpw, &nj, &rw);
+    wo_geometry(w, n_att, &rpw, &nj, &rw, 8);
     *grid = n_att + extra_workgroups(n_att);
     if (rpw_out) *rpw_out = rpw;
     return two ? (const void*)pick_attn_wo<128, 2>(nj, rw, mode) : (const void*)pick_attn_wo<128, 1>(nj, rw, mode);
