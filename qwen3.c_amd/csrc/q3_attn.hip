@@ -49,6 +49,12 @@ namespace q3k {
 
 typedef __attribute__((address_space(1))) unsigned g_u32;
 
+// A wait inside a launch gives up after this much DEVICE time (s_memrealtime, 100 MHz) unless the launch carries its own
+// bound (WoView::wait_ticks): far beyond anything a healthy launch takes, short of what a watchdog calls a hung GPU.
+#ifndef Q3_WAIT_TICKS
+#define Q3_WAIT_TICKS 500000000ull   // 5 s
+#endif
+
 // a word that an EARLIER launch wrote (position, step counter), fetched by s_load through the scalar cache
 // (volatile: the request stays where it is written, ahead of the vector loads; only the wait moves to the use)
 __device__ __forceinline__ int ld_scalar(const int* p) {
@@ -173,6 +179,89 @@ __device__ __forceinline__ void merge_partials(const Attn& a, int h, int nchunks
         out_codes<PUB>(a, tag, (size_t)h * HD + 4 * lane, packed);
         if ((lane & 15) == 0) out_scale<PUB>(a, tag, (size_t)h * HD + 4 * lane, scale);
         if (a.of) *reinterpret_cast<float4*>(a.of + (size_t)h * HD + 4 * lane) = y;
+    }
+}
+
+// The same merge from partials published as {tag, value} granules (k_attn_wo, ATT_MERGE): the workgroup of chunk slot 0
+// re-reads the granules of every chunk of the head until all carry this step's tag -- ONE round trip when the other
+// chunks are through (they run the same program on the same amount of data), against a drain of the stores, a ticket
+// round trip and a fetch round trip for the counter form.  Arithmetic: merge_partials' (q3_numerics.h "attention").
+template <int HD>
+__device__ __forceinline__ void merge_partials_granules(const Attn& a, int h, int nchunks, int lane, unsigned tag) {
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    constexpr int L4 = HD / 4;
+    constexpr int ST = HD + 2;
+    constexpr int AH = Q3_ATT_LONG / Q3_ATT_CHUNK;      // every chunk the in-launch merge ever sees
+    constexpr int BR = 8;                                // rows per batch of the sweep (64 registers of granules)
+    const g_u64* base = (const g_u64*)(a.pg + (size_t)h * a.max_chunks * ST);
+    const int l4 = lane < L4 ? lane : L4 - 1;            // (lanes past the head re-read its last slice: unconditional loads)
+    const int cm = lane < nchunks ? lane : nchunks - 1;
+    const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+    // One sweep brings the (m, l) pairs (one chunk per lane) and the first eight O rows; its loads are all in flight at
+    // once, so when the other chunks are through (they run the same program on as much data) the merge costs ONE round trip.
+    float2 ml0 = make_float2(-3.0e38f, 0.0f);
+    float M = 0.0f, wc = 0.0f, wl = 0.0f;
+    float L = 0.0f;
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < AH && k0 < nchunks; k0 += BR) {       // (wave-uniform: the second batch only beyond eight chunks)
+        unsigned long long gx[BR][4];
+        for (;;) {
+            unsigned long long gm = 0, gl = 0;
+            if (k0 == 0) {
+                gm = __hip_atomic_load(base + (size_t)cm * ST + HD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gl = __hip_atomic_load(base + (size_t)cm * ST + HD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < BR; k++) {
+                const g_u64* row = base + (size_t)(k0 + k < nchunks ? k0 + k : nchunks - 1) * ST + 4 * l4;
+#pragma unroll
+                for (int e = 0; e < 4; e++) gx[k][e] = __hip_atomic_load(row + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool hit = k0 != 0 || ((unsigned)(gm >> 32) == tag && (unsigned)(gl >> 32) == tag);
+#pragma unroll
+            for (int k = 0; k < BR; k++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) hit = hit && (unsigned)(gx[k][e] >> 32) == tag;
+            }
+            if (__all(hit)) {
+                if (k0 == 0) {
+                    if (lane < nchunks) ml0 = make_float2(__uint_as_float((unsigned)gm), __uint_as_float((unsigned)gl));
+                    M = wave_max(ml0.x);
+                    if (lane < nchunks) {
+                        wc = q3_expf(ml0.x - M);
+                        wl = wc * ml0.y;
+                    }
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t_wait > Q3_WAIT_TICKS) return;      // (the consumers give up as well and raise the flag)
+        }
+#pragma unroll
+        for (int k = 0; k < BR; k++) {
+            if (k0 + k < nchunks) {
+                const float wk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wc), (k0 + k) & 63));
+                const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), (k0 + k) & 63));
+                L = L + t;
+                A.x = A.x + wk * __uint_as_float((unsigned)gx[k][0]);
+                A.y = A.y + wk * __uint_as_float((unsigned)gx[k][1]);
+                A.z = A.z + wk * __uint_as_float((unsigned)gx[k][2]);
+                A.w = A.w + wk * __uint_as_float((unsigned)gx[k][3]);
+            }
+        }
+    }
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < L4) {
+        y.x = A.x / L;
+        y.y = A.y / L;
+        y.z = A.z / L;
+        y.w = A.w / L;
+    }
+    float scale;
+    const int packed = quantize_group16(y, scale);
+    if (lane < L4) {
+        out_codes<true>(a, tag, (size_t)h * HD + 4 * lane, packed);
+        if ((lane & 15) == 0) out_scale<true>(a, tag, (size_t)h * HD + 4 * lane, scale);
     }
 }
 
@@ -575,7 +664,22 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
                 o.y = acc.y + lane_xor_f<32>(acc.y);
                 o.z = acc.z + lane_xor_f<32>(acc.z);
                 o.w = acc.w + lane_xor_f<32>(acc.w);
-                if (multi) {
+                if (PUB && multi == ATT_MERGE) {
+                    // the partial as {tag, value} granules: the workgroup of slot 0 polls them (merge_partials_granules)
+                    typedef __attribute__((address_space(1))) unsigned long long g_u64w;
+                    g_u64w* pg = (g_u64w*)(a.pg + ((size_t)h * a.max_chunks + c) * (HD + 2));
+                    const unsigned long long tg = (unsigned long long)tag << 32;
+                    if (lane < L4) {
+                        __hip_atomic_store(pg + 4 * lane + 0, tg | __float_as_uint(o.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pg + 4 * lane + 1, tg | __float_as_uint(o.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pg + 4 * lane + 2, tg | __float_as_uint(o.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pg + 4 * lane + 3, tg | __float_as_uint(o.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) {
+                            __hip_atomic_store(pg + HD, tg | __float_as_uint(m[hi]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(pg + HD + 1, tg | __float_as_uint(lsum[hi]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                } else if (multi) {
                     if (lane < L4) {
                         // write-through (sc1) stores: another workgroup of this launch reads them
                         float* pp = a.part + ((size_t)h * a.max_chunks + c) * (HD + 2);
@@ -602,7 +706,13 @@ __device__ __forceinline__ bool attn_body(const Attn& a, int multi_rt, int g, in
                 }
             }
         }
-        if (multi == ATT_MERGE) {
+        if (PUB && multi == ATT_MERGE) {
+            // (nslots >= nchunks in this shape: every workgroup owns one chunk, and slot 0 always has one)
+            if (slot == 0) {
+                for (int i = wave; i < kv_mul; i += 4) merge_partials_granules<HD>(a, g * kv_mul + i, nchunks, lane, tag);
+                last_flag = 1;
+            }
+        } else if (multi == ATT_MERGE) {
             // Publish: every storing wave drains its write-through stores, the workgroup meets,
             // ONE lane takes a ticket (Guideline 16, counter form).  The workgroup whose ticket
             // is the last of its kv head merges the partials of the head's chunks right here.
@@ -671,9 +781,6 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi, int rows_
 // A wait inside a launch gives up after this much DEVICE time (s_memrealtime, 100 MHz): far beyond anything a
 // healthy launch takes -- also when another process's kernels hold the attention workgroups' CUs for a while -- and
 // short of what a watchdog would call a hung GPU.  (A count of polls would expire sooner the faster the polls return.)
-#ifndef Q3_WAIT_TICKS
-#define Q3_WAIT_TICKS 500000000ull   // 5 s
-#endif
 
 // The attention chain does all its memory round trips in its first ~3.5 us (position, q/k/v, K tile, V tile); weight
 // traffic from the rest of the chip during that time raises their latency (profiles/r03_l2_warm_experiment.md: +1.3 us

@@ -72,6 +72,9 @@ struct Attn {
     unsigned long long* og;
     const unsigned* epoch;
     unsigned layer_tag;
+    // k_attn_wo, in-launch-merge shape: the chunk partials as granules too, [n_heads][max_chunks][hd+2] -- the workgroup
+    // of chunk slot 0 merges a kv head's chunks as soon as their granules carry the tag (no drain, no ticket)
+    unsigned long long* pg;
 };
 // k (head norm + RoPE) and v of `ntok` consecutive positions into the cache (reference forward.c:270-286),
 // ahead of a batched attn(): qkv rows of stride zs_qkv, (cos,sin) rows of stride hd, positions from ctl[t].pos

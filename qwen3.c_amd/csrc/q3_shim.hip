@@ -128,6 +128,7 @@ struct Dev {
     unsigned* tickets = nullptr;  // attention chunk tickets, [KV], zero between launches
     unsigned* epoch = nullptr;    // step counter advanced by k_begin: tags the in-launch hand-offs of k_attn_wo
     unsigned long long* att_g = nullptr;   // attention output as {tag, value} granules [P/4 + P/64] (fused launch)
+    unsigned long long* part_g = nullptr;  // chunk partials as {tag, value} granules [H][max_chunks][hd+2] (k_attn_wo, in-launch merge)
     unsigned* err_host = nullptr; // host-mapped: [0] set by a consumer whose bounded wait gave up
     // What has been queued since the last synchronisation that found err_host clear, as closures that queue it again:
     // when a hand-off inside a fused launch times out, the Model drops to the separate launches (fuse = false, graphs
@@ -437,6 +438,8 @@ Dev* attach(Model* m, const AttachOpts& opt = AttachOpts()) {
     HIPCHK(hipMemsetAsync(d->epoch, 0, 4 * sizeof(unsigned), d->st));
     d->att_g = dalloc<unsigned long long>(d, (size_t)d->P / 4 + d->P / 64);
     HIPCHK(hipMemsetAsync(d->att_g, 0, ((size_t)d->P / 4 + d->P / 64) * 8, d->st));     // tag 0 = never a step's tag
+    d->part_g = dalloc<unsigned long long>(d, (size_t)d->H * d->max_chunks * (d->hd + 2));
+    HIPCHK(hipMemsetAsync(d->part_g, 0, (size_t)d->H * d->max_chunks * (d->hd + 2) * 8, d->st));
     HIPCHK(hipHostMalloc((void**)&d->err_host, 4 * sizeof(unsigned), hipHostMallocMapped));
     memset(d->err_host, 0, 4 * sizeof(unsigned));
     {
@@ -645,7 +648,7 @@ void enqueue_layer(Dev* d, int l, q3k::AttMode mode, int stream = 0, int rows_ca
         if (d->fuse && l < 255) {
             q3k::WoView w = wo_view(d, l);
             if (mode == q3k::ATT_LONG) w.delay = 0;       // the merge is one round trip long: no reason to hold Wo back
-            a.og = d->att_g; a.epoch = d->epoch; a.layer_tag = w.layer_tag;
+            a.og = d->att_g; a.epoch = d->epoch; a.layer_tag = w.layer_tag; a.pg = d->part_g;
             if (q3k::attn_wo_supported(a, w, d->chunk_slots, mode)) {
                 // attention AND Wo + residual in one launch (forward.c:267-298)
                 Timed t(d, "attn_wo", q3_gemv_bytes(d->dim, d->P));
