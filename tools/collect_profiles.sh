@@ -10,7 +10,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 REPO=$(dirname "$OUT")/..
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp Q3_GRAPH=0
-B="--no-cpu-baseline --no-roofline --no-sweep --no-dropin"
+B="--no-cpu-baseline --no-roofline --no-sweep --no-dropin --no-models"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o k --output-format csv -- python3 "$REPO/bench.py" --steps 64 --warmup 8 $B > "$OUT/stats.log" 2>&1
 echo stats done
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" -o f --output-format csv -- python3 "$REPO/bench.py" --steps 16 --warmup 4 $B > "$OUT/fetch.log" 2>&1
