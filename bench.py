@@ -542,7 +542,7 @@ def main():
             ach = round(dom_bytes / us_best / 1e3, 1)
             traffic, traffic_check = None, None
             try:   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]["gateup"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))["kernels"]["gateup"]
                 if args.model == "4B":
                     traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
                     # in-run check: the bytes this run prices the launch at against the committed counter figure
@@ -553,7 +553,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "k_gemv3<PRO_NORM,EPI_SWIGLU,3,8> (gate/up GEMV)",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "traffic_source": "profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+                               "traffic_source": "profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
                                                  "of this workload (FETCH_SIZE doubled per the gfx950 note), committed -- not re-measured by this run",
                                "traffic_check": traffic_check,
                                "timing": "in-kernel device clock (s_memrealtime, first workgroup in .. last out) of the "
