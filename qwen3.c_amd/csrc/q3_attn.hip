@@ -274,6 +274,12 @@ __device__ __forceinline__ void merge_partials_granules(const Attn& a, int h, in
 // meets the compute waves at the barriers the one-role kernel has (K tile ready, V tile ready) once its share of
 // the tile has landed (counted vmcnt).  Row `pos` of the owning chunk is not in the cache yet: the DMA brings a stale
 // row, and the compute side overwrites it behind one extra barrier that only the owning workgroup takes.
+__device__ __forceinline__ void hold_back(int ticks) {
+    if (ticks <= 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 template <int HD>
@@ -297,6 +303,11 @@ __device__ __forceinline__ void tile_loader(const Attn& a, int g, int slot, int 
     __builtin_amdgcn_s_barrier();             // E: the compute waves have their few requests in the queue
     if (slot >= sure_slots && slot * CH > pos) return;
     tile_dma<HD>(a.kc + cbase + (size_t)slot * CH * HD, Ks, uwave, lane);
+    // Two workgroups share a CU, and a CU returns loads in issue order: with V requested right behind K, the second
+    // workgroup's K tile queues behind the first one's V tile, which nobody needs before its scores are done.  Holding the
+    // V requests back (1.5 us: 548 -> 554 tok/s at 4096 positions; holding the K requests back as well, so that both
+    // workgroups' small requests go first, loses 1-2 %) puts both K tiles first.
+    hold_back(a.v_hold);
     tile_dma<HD>(a.vc + cbase + (size_t)slot * CH * HD, Vs, uwave, lane);
     const int T = pos + 1;
     const int nchunks = (T + CH - 1) / CH;
@@ -786,11 +797,6 @@ __global__ __launch_bounds__(256, 2) void k_attn(Attn a_in, int multi, int rows_
 // traffic from the rest of the chip during that time raises their latency (profiles/r03_l2_warm_experiment.md: +1.3 us
 // on the stage for 11 MB).  So the consumer workgroups sit out `ticks` x 10 ns of the device clock before they
 // request their Wo rows; the rows are still in registers ~1.5 us before the attention output appears.
-__device__ __forceinline__ void hold_back(int ticks) {
-    if (ticks <= 0) return;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)ticks) __builtin_amdgcn_s_sleep(8);
-}
 
 #ifdef Q3_ATTN_STAMPS
 // consumer workgroup wb leaves its marks behind the attention workgroups': stamps[8 * (n_att + wb) + i]
@@ -1301,7 +1307,7 @@ __global__ __launch_bounds__(64) void k_attn_merge(Attn a_in) {
 // outputs, as k_attn_merge) while the other CUs pull their Wo rows into registers, then take the merged output as
 // tagged granules (wo_role) -- instead of a merge launch, a boundary and a Wo launch.
 template <int HD, int NJ, int RW>
-__global__ __launch_bounds__(256, 2) void k_merge_wo(Attn a, WoView w) {
+__global__ __launch_bounds__(512) void k_merge_wo(Attn a, WoView w) {
     __shared__ __attribute__((aligned(16))) int8_t lq[4096];
     __shared__ __attribute__((aligned(16))) float ls[64];
     __shared__ int flag;
@@ -1312,7 +1318,7 @@ __global__ __launch_bounds__(256, 2) void k_merge_wo(Attn a, WoView w) {
         if (threadIdx.x < 64) merge_group<HD, true>(a, b / GPH, b % GPH, threadIdx.x);
         return;
     }
-    wo_role<NJ, RW>(w, b - nm, lq, ls, &flag);
+    wo_role<NJ, RW, 8>(w, b - nm, lq, ls, &flag);
 }
 
 // ---- batched prompt ingestion: the k/v rows of a run of positions, ahead of a batched attn() ----
@@ -1372,10 +1378,10 @@ bool attn_wo_supported(const Attn& a, const WoView& w, int chunk_slots, AttMode 
     if (!(a.nz <= 1 && !a.of && !a.prepared && a.n_heads / a.n_kv <= Q3_MAXG && a.hd == 128)) return false;
     if (!w.W || !a.og || !a.epoch) return false;
     const int producers = mode == ATT_LONG ? merge_workgroups(a) : a.n_kv * attn_slots(chunk_slots, mode);
-    if (!(w.n == a.n_heads * a.hd && w.n <= 4096 && producers < cu_count() && wo_geometry(w, producers, &rpw, &nj, &rw, mode == ATT_LONG ? 4 : 8))) return false;
+    if (!(w.n == a.n_heads * a.hd && w.n <= 4096 && producers < cu_count() && wo_geometry(w, producers, &rpw, &nj, &rw, 8))) return false;
     int grid = 0;
     const void* kern = fused_kernel(a, w, chunk_slots, mode, &grid, nullptr);
-    if (!grid_resident(kern, grid, mode == ATT_LONG ? 256 : 512)) {
+    if (!grid_resident(kern, grid, 512)) {
         static bool told = false;
         if (!told) fprintf(stderr, "[q3hip] the fused attention + Wo launch (%d workgroups) would not be resident at once on this device: separate launches\n", grid);
         told = true;
@@ -1460,9 +1466,9 @@ template <int HD>
 static void launch_merge_wo(const Attn& a, WoView w, hipStream_t st) {
     int rpw = 1, nj = 1, rw = 1;
     const int nm = merge_workgroups(a), nwo = extra_workgroups(nm);
-    wo_geometry(w, nm, &rpw, &nj, &rw);
+    wo_geometry(w, nm, &rpw, &nj, &rw, 8);
     w.rpw = rpw;
-    const dim3 grid(nm + nwo), blk(256);
+    const dim3 grid(nm + nwo), blk(512);
     const MergeWoFn fn = pick_merge_wo<HD>(nj, rw);
     hipLaunchKernelGGL(fn, grid, blk, 0, st, a, w);
 }
@@ -1483,7 +1489,7 @@ static const void* fused_kernel(const Attn& a, const WoView& w, int chunk_slots,
     const bool two = a.n_heads / a.n_kv > 4;
     if (mode == ATT_LONG) {
         const int nm = merge_workgroups(a);
-        wo_geometry(w, nm, &rpw, &nj, &rw);
+        wo_geometry(w, nm, &rpw, &nj, &rw, 8);
         *grid = nm + extra_workgroups(nm);
         if (rpw_out) *rpw_out = rpw;
         return (const void*)pick_merge_wo<128>(nj, rw);

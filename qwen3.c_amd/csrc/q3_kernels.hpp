@@ -75,6 +75,7 @@ struct Attn {
     // k_attn_wo, in-launch-merge shape: the chunk partials as granules too, [n_heads][max_chunks][hd+2] -- the workgroup
     // of chunk slot 0 merges a kv head's chunks as soon as their granules carry the tag (no drain, no ticket)
     unsigned long long* pg;
+    int v_hold;          // k_attn_long: device-clock ticks (10 ns) the loader waves hold their V-tile requests back behind the K tile's
 };
 // k (head norm + RoPE) and v of `ntok` consecutive positions into the cache (reference forward.c:270-286),
 // ahead of a batched attn(): qkv rows of stride zs_qkv, (cos,sin) rows of stride hd, positions from ctl[t].pos

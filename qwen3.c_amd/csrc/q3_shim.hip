@@ -591,6 +591,7 @@ q3k::Attn attn_args(Dev* d, int l, int stream = 0) {
     a.tickets = d->tickets; a.oq = d->att_q; a.os = d->att_s;
     a.of = nullptr; a.qdbg = nullptr; a.prepared = 0; a.stamps = d->stamps;
     a.n_heads = d->H; a.n_kv = d->KV; a.hd = d->hd; a.seq_len = d->seq_pad; a.max_chunks = d->max_chunks;
+    { static const int vh = getenv("Q3_V_HOLD") ? atoi(getenv("Q3_V_HOLD")) : 150; a.v_hold = vh; }
     return a;
 }
 
