@@ -2,8 +2,10 @@
 // Arithmetic contract: q3_numerics.h.  All cross-lane traffic uses the cheapest
 // gfx950 instruction that realises the contract's pairing:
 //   xor 1, 2      DPP quad_perm (no LDS hardware involved)
-//   xor 4, 8, 16  ds_swizzle_b32 in bit-mask mode (LDS crossbar, no address VGPR)
-//   xor 32        v_permlane32_swap
+//   xor 4         two DPP row rotations under bank masks
+//   xor 8         DPP row_ror:8
+//   xor 16, 32    v_permlane16_swap / v_permlane32_swap
+// (until round 4 xor 4, 8, 16 went through ds_swizzle_b32: the LDS crossbar, ~100 cycles per dependent level)
 // (hipcc lowers __shfl_xor to ds_bpermute_b32 with a computed address for all of them.)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -25,9 +27,23 @@ __device__ __forceinline__ int lane_xor_i(int v) {
     } else if constexpr (M == 32) {
         auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
         return (int)((threadIdx.x & 32) ? r[0] : r[1]);
+#ifndef Q3_XOR_SWIZZLE          // (round 4: no trip through the LDS crossbar for xor 16 / 8 / 4 either -- ~100 cycles of
+                                //  latency per dependent butterfly level against ~10; -DQ3_XOR_SWIZZLE restores ds_swizzle)
+    } else if constexpr (M == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);     // r[0] = rows 0,0,2,2; r[1] = rows 1,1,3,3
+        return (int)((threadIdx.x & 16) ? r[0] : r[1]);
+    } else if constexpr (M == 8) {
+        return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);      // row_ror:8 (lane i of a row of 16 gets lane i ^ 8)
+    } else {
+        // xor 4 = rotate a row of 16 by 12 in the banks whose lanes have bit 2 clear (0, 2), by 4 in the others (1, 3)
+        int t = __builtin_amdgcn_update_dpp(v, v, 0x12C, 0xF, 0x5, false);
+        return __builtin_amdgcn_update_dpp(t, v, 0x124, 0xF, 0xA, false);
+    }
+#else
     } else {
         return __builtin_amdgcn_ds_swizzle(v, (M << 10) | 0x1F);
     }
+#endif
 }
 template <int M>
 __device__ __forceinline__ float lane_xor_f(float v) {
