@@ -857,22 +857,21 @@ __device__ __forceinline__ void wo_role(const WoView& w, int wb, int8_t* lq, flo
         // Every load below is unconditional (indices clamped to a granule of the same kind; the compare is masked
         // instead): behind `if (i < ncode)` each load became an exec-masked block ending in s_waitcnt vmcnt(0), and
         // a sweep cost one memory round trip PER GRANULE of a thread instead of one in all.
-        // Poll (w.poll, experiments): 0 = every wave re-reads its lanes' first code granules (granules 0..255: two kv
-        // heads' worth); 1 = every wave the scale granules; 2 = ONE wave per workgroup polls a 64-granule block picked
-        // by the workgroup index (the others park at the barrier): 1/4 of the requests, spread over all lines.
-        const int pm = w.poll & 3;
-        int is = pm == 1 ? ncode + tid % nscale : (pm == 2 ? ((wb * 64) % (ncode + nscale - 63)) + lane : (tid < ncode ? tid : ncode - 1));
-        const int nap = w.poll >> 2;
-        if (pm != 2 || uwave == 0) {
+        // ONE wave per workgroup polls, on a 64-granule block picked by the workgroup index (the polls of the 248 waiting
+        // workgroups spread over all lines of the granule array); the other waves are parked at the barrier.  Measured
+        // against every wave polling its first code granules (the same 16 lines chip-wide: +0.6 us per hand-off) and
+        // against every wave polling the scale granules (4 lines: +1.9 us): profiles/r04_ab_runs.txt.
+        if (uwave == 0) {
+            const int is = ((wb * 64) % (ncode + nscale - 63)) + lane;
             for (;;) {
                 const unsigned long long x = __hip_atomic_load(gr + is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool hit = (unsigned)(x >> 32) == tag;
                 if (__all(hit)) break;
-                if (nap == 0) __builtin_amdgcn_s_sleep(2); else if (nap == 1) __builtin_amdgcn_s_sleep(8); else if (nap == 2) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(100);
+                __builtin_amdgcn_s_sleep(2);
                 if (__builtin_amdgcn_s_memrealtime() - t_wait > w.wait_ticks) { ok = 0; break; }
             }
         }
-        if (pm == 2) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         WSTAMP(3);
         while (ok) {
             unsigned long long x[NG];

@@ -115,7 +115,6 @@ struct WoView {
     unsigned* err;        // host-mapped word, set to 1 when a bounded wait gives up
     unsigned long long* stamps;   // diagnostic builds only (-DQ3_ATTN_STAMPS): eight device-clock marks per consumer workgroup
     int delay;            // device-clock ticks (10 ns) the extra workgroups hold their weight requests back after entry
-    int poll;             // experiments (Q3_WO_POLL): how the consumers wait, see wo_role
     unsigned long long wait_ticks;   // a consumer gives up after this much device time (10-ns ticks; 5 s unless Q3_WAIT_TICKS says otherwise: tests)
 };
 // rows per consumer workgroup / whether the fused launch covers this shape (else: attn() then gemv())

@@ -618,7 +618,6 @@ q3k::WoView wo_view(Dev* d, int l) {
     // separate launches: enqueue_layer)
     w.gran = d->att_g; w.epoch = d->epoch; w.layer_tag = (unsigned)l + 1u;
     w.delay = d->pf_delay;
-    { static const int pm = getenv("Q3_WO_POLL") ? atoi(getenv("Q3_WO_POLL")) : 2; w.poll = pm; }
     { static const unsigned long long wt = getenv("Q3_WAIT_TICKS") ? strtoull(getenv("Q3_WAIT_TICKS"), nullptr, 10) : 500000000ull; w.wait_ticks = wt; }
     w.stamps = d->stamps;
     HIPCHK(hipHostGetDevicePointer((void**)&w.err, d->err_host, 0));
