@@ -756,7 +756,9 @@ void sync_checked(Dev* d) {
 }
 // remember how to queue a piece of work again (no-op while a replay is running: the jobs run as they are)
 void remember(Dev* d, std::function<void()> job) {
-    if (!d->replaying) d->redo.push_back(std::move(job));
+    if (d->replaying || !d->fuse) return;           // (without fused launches there is no hand-off that could give up)
+    d->redo.push_back(std::move(job));
+    if (d->redo.size() >= 4096) sync_checked(d);     // a caller that queues without ever synchronising: settle what there is
 }
 
 void fetch_logits_async(Dev* d) {
