@@ -74,6 +74,10 @@ struct Pipe {
     bool on = false;
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
+    // Q3_PIPE_SELF=1 with world 1: a ONE-rank RCCL communicator whose rank sends the tick's message to itself -- the
+    // transport of the pipeline (communicator set-up, grouped ncclSend/ncclRecv on the launch stream between graph
+    // replays) exercised on the single GPU a test box has
+    bool self = false;
 };
 Pipe g_pipe;
 
@@ -1220,7 +1224,7 @@ void pipeline_tick(Dev* d, int first_token, int pos0, int s, int k) {
         HIPCHK(hipMemcpyAsync(d->xout, d->x, (size_t)d->dim * 4, hipMemcpyDeviceToDevice, d->st));
     } else {
         // greedy pick on the device; with one stage it feeds the next step directly
-        int* dst = N == 1 ? tok_slot_in : tok_slot_out;
+        int* dst = (N == 1 && !g_pipe.self) ? tok_slot_in : tok_slot_out;
         if (d->samp_on) q3k::sample(d->logits, d->V, d->samp_t, d->samp_p, 0.0f, d->seed_dev, d->sb, dst, nullptr, d->st);
         else q3k::argmax(d->logits, d->V, d->amax_scratch, dst, nullptr, d->st);
         hipLaunchKernelGGL(k_log_token, dim3(1), dim3(1), 0, d->st, dst, d->ptokens + (size_t)s * d->ptokens_cap + k);
@@ -1260,7 +1264,7 @@ int pipeline_run(Dev* d, int first_token, int pos0, int nsteps, int streams = 0)
             pipeline_tick(d, first_token, pos0, s, k);
             ticks++;
         }
-        if (d->world > 1 && t < T - 1) ring_exchange(d, t);
+        if ((d->world > 1 || g_pipe.self) && t < T - 1) ring_exchange(d, t);
     }
     return ticks;
 }
@@ -1991,7 +1995,7 @@ int q3_pipeline_unique_id(void* id_bytes) {
 
 /* ranks of the RCCL communicator the pipeline runs on (1 = no pipeline) */
 int q3_pipeline_size(void) {
-    if (!g_pipe.on || !g_pipe.comm) return 1;
+    if (!(g_pipe.on || g_pipe.self) || !g_pipe.comm) return 1;
     int n = 0;
     if (ncclCommCount(g_pipe.comm, &n) != ncclSuccess) return -1;
     return n;
@@ -2012,7 +2016,8 @@ int q3_pipeline_init(int rank, int world, const void* id_bytes) {
     g_pipe.rank = rank;
     g_pipe.world = world;
     g_pipe.on = world > 1;
-    if (world > 1) {
+    g_pipe.self = world == 1 && getenv("Q3_PIPE_SELF") && atoi(getenv("Q3_PIPE_SELF")) != 0;
+    if (world > 1 || g_pipe.self) {
         setenv("NCCL_SOCKET_IFNAME", "lo", 0);
         ncclUniqueId id;
         memcpy(&id, id_bytes, sizeof(id));
@@ -2045,6 +2050,7 @@ void q3_pipeline_shutdown(void) {
         g_pipe.comm = nullptr;
     }
     g_pipe.on = false;
+    g_pipe.self = false;
     g_pipe.world = 1;
     g_pipe.rank = 0;
 }
