@@ -746,8 +746,10 @@ bool handoff_failed(Dev* d) {
 void wait_step(Dev* d);
 void sync_checked(Dev* d) {
     wait_step(d);
+    // (a stage of a pipeline cannot redo its ticks alone: the other stages have moved on)
+    if (d->world > 1 && d->err_host && *(volatile unsigned*)d->err_host)
+        Q3_DIE("an in-launch hand-off timed out on one stage of a %d-stage pipeline: restart with Q3_FUSE=0", d->world);
     if (handoff_failed(d)) {
-        if (d->world > 1) Q3_DIE("an in-launch hand-off timed out on one stage of a %d-stage pipeline: restart with Q3_FUSE=0", d->world);
         std::vector<std::function<void()>> jobs;
         jobs.swap(d->redo);
         d->replaying = true;
